@@ -1,0 +1,64 @@
+"""Recipes that build the checker: the C oracle (gcc) and, when /root/reference is present, the
+reference's own Newton loop linked against the oracle's tape entry points (oracle/_ref/).
+
+Outputs: oracle/libtc_oracle.so and oracle/_ref/libipmref_<tag>.so (both git-ignored, both
+travel to the GPU box).  No reference source is copied: ipmPD_CSsolver.c is compiled from
+/root/reference/lib where it lies, with the -D block of cmex2optimizeCS.m:303-331.
+"""
+import os
+import subprocess
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+REF_SOLVER = "/root/reference/lib/ipmPD_CSsolver.c"
+
+
+def _run(cmd):
+    r = subprocess.run(cmd, capture_output=True, text=True)
+    if r.returncode:
+        raise RuntimeError("command failed: %s\n%s\n%s" % (" ".join(cmd), r.stdout, r.stderr))
+
+
+def build_oracle(opt="-O1"):
+    """-O1 is the reference's "fastest run-time" setting (examples/l1l2estimationCS.m:22-25).
+    -ffp-contract=off: the reference build targets plain x86-64 (no FMA)."""
+    out = os.path.join(HERE, "libtc_oracle.so")
+    src = os.path.join(HERE, "tc_oracle.c")
+    if os.path.exists(out) and os.path.getmtime(out) >= max(
+            os.path.getmtime(src), os.path.getmtime(os.path.join(HERE, "tc_oracle.h"))):
+        return out
+    _run(["gcc", opt, "-ffp-contract=off", "-std=gnu99", "-fPIC", "-shared", "-I", HERE, src, "-o", out, "-lm"])
+    return out
+
+
+def _fmt(v):
+    if isinstance(v, float):
+        return "%e" % v          # cmex2optimizeCS.m:307-320 prints doubles with sprintf('%e')
+    return str(int(v))
+
+
+def build_ref(tag, defines, opt="-O1"):
+    """Compile the reference Newton loop for one problem's #define block; returns the .so path
+    or None when /root/reference is absent (GPU box)."""
+    out = os.path.join(HERE, "_ref", "libipmref_%s.so" % tag)
+    if not os.path.exists(REF_SOLVER):
+        return out if os.path.exists(out) else None
+    os.makedirs(os.path.join(HERE, "_ref"), exist_ok=True)
+    names = ["nU", "nG", "nF", "gradTolerance", "addEye2HessianUtolerance", "equalTolerance",
+             "desiredDualityGap", "scaleCost", "scaleInequalities", "scaleEqualities", "alphaMin",
+             "alphaMax", "coupledAlphas", "setAddEye2Hessian", "adjustAddEye2Hessian", "useInertia",
+             "muFactorAggressive", "muFactorConservative", "delta", "skipAffine",
+             "smallerNewtonMatrix", "useLDL", "useUmfpack", "allowSave", "debugConvergence",
+             "profiling"]
+    dflags = ["-D%s=%s" % (k, _fmt(defines[k])) for k in names]
+    dflags += ["-DverboseLevel=0", "-DEXPORT=", '-DsaveNamePrefix="x"']
+    obj = out[:-3] + ".o"
+    # the -D block only applies to the reference file; the glue and interpreter get none
+    _run(["gcc", "-w", opt, "-ffp-contract=off", "-std=gnu99", "-fPIC", "-c"] + dflags + [REF_SOLVER, "-o", obj])
+    _run(["gcc", opt, "-ffp-contract=off", "-std=gnu99", "-fPIC", "-shared", "-I", HERE, obj,
+          os.path.join(HERE, "ref_glue.c"), os.path.join(HERE, "tc_oracle.c"), "-o", out, "-lm"])
+    os.remove(obj)
+    return out
+
+
+if __name__ == "__main__":
+    print(build_oracle())

@@ -1,0 +1,57 @@
+/* ORACLE - test infrastructure only.
+ *
+ * Glue that lets the reference's own Newton loop, /root/reference/lib/ipmPD_CSsolver.c compiled
+ * from where it lies, drive the oracle's tape interpreter: it defines the `extern void xxx__()`
+ * tape entry points that file expects (ipmPD_CSsolver.c:28-51) by forwarding to tc_oracle.c.
+ * In the reference these functions are MATLAB-generated code (not producible here: no MATLAB),
+ * so this build pins ONLY the Newton-loop control flow of tco_solve(), not tape construction.
+ */
+#include <string.h>
+#include "tc_oracle.h"
+
+static tco_t *g;
+void tcref_bind(tco_t *t) { g = t; }
+
+#define COPY(fn) void fn(void) { tco_copy(g, tco_entry(g, #fn)); }
+#define SET(fn) void fn(const double *x) { tco_set(g, tco_entry(g, #fn), x); }
+#define GET1(fn) void fn(double *x) { tco_get_flat(g, tco_entry(g, #fn), x); }
+
+COPY(initPrimal__)
+COPY(initDualEq__)
+COPY(initDualEqX__)
+COPY(initDualIneq__)
+COPY(updatePrimalDual__)
+COPY(scaleIneq__)
+COPY(scaleCost__)
+SET(setAddEye2HessianU__)
+SET(setAddEye2HessianEq__)
+SET(setAlphaPrimal__)
+SET(setAlphaDualEq__)
+SET(setAlphaDualIneq__)
+SET(setMu__)
+GET1(getDirectionError__)
+GET1(getScale4Cost__)
+GET1(getJ__)
+GET1(getNorminf_G__)
+GET1(getNorminf_Grad__)
+GET1(getCurvature__)
+GET1(getMinF_s__)
+void getGapMinFMinLambda__(double *gap, double *ineq, double *dual) {
+  double t[3];
+  tco_get_flat(g, tco_entry(g, "getGapMinFMinLambda__"), t);
+  *gap = t[0];
+  *ineq = t[1];
+  *dual = t[2];
+}
+void getMaxAlphas_s__(double *alphaPrimal, double *alphaDual) {
+  double t[2];
+  tco_get_flat(g, tco_entry(g, "getMaxAlphas_s__"), t);
+  *alphaPrimal = t[0];
+  *alphaDual = t[1];
+}
+void getHessInertia__(double *mp, double *mn) {
+  double t[2];
+  tco_get_flat(g, tco_entry(g, "getHessInertia__"), t);
+  *mp = t[0];
+  *mn = t[1];
+}

@@ -1,0 +1,179 @@
+"""Solver generator front door: ``cmex2optimizeCS`` with a HIP back-end.
+
+Mirrors /root/reference/lib/cmex2optimizeCS.m (parameter names and meaning from
+lib/private/parameters4optimize.m:12-168 and parameters4all.m:15-630): takes an objective,
+optimization variables, constraints, parameters and output expressions written with
+:mod:`tenscalc_amd.tcalculus`, builds the primal-dual interior-point tape and returns a
+:class:`SolverSpec`.  ``SolverSpec.build()`` lowers the tape to a HIP class library
+(:mod:`tenscalc_amd.hip_emitter`) and ``SolverSpec.load()`` returns an object with the
+reference class surface ``setP_*/setV_*/solve/getOutputs`` extended by a trailing batch
+dimension.
+"""
+from __future__ import annotations
+
+import re
+
+from . import tcalculus as tc
+from .csparse import CSparse
+from .ipm_assembly import ipmPD_CStimesLambda
+from .tcalculus import Tvariable, Tzeros, cat, reshape, substitute
+
+__all__ = ["cmex2optimizeCS", "SolverSpec"]
+
+
+def packExpressions(exprs):
+    """lib/packExpressions.m"""
+    if not exprs:
+        return Tzeros((0,))
+    return cat(1, *[reshape(e, (tc._prod(e.size),)) for e in exprs])
+
+
+def packVariables(variables, name, *exprs):
+    """lib/packVariables.m: one column vector replaces the listed variables."""
+    n = 0
+    where = []
+    for v in variables:
+        if v.op != "variable":
+            raise ValueError(f"Can only pack variables (not {v.op})")
+        ln = tc._prod(v.size)
+        where.append((n, n + ln))
+        n += ln
+    out = Tvariable(name, (n,))
+    repl = [reshape(out[a:b], v.size) for v, (a, b) in zip(variables, where)]
+    res = [substitute(e, list(variables), repl) for e in exprs]
+    return (out, where) + tuple(res)
+
+
+def parseConstraints(code, classname, constraints):
+    """lib/private/parseConstraints.m:74-135"""
+    Gc, Fc, nus, lambdas = [], [], [], []
+    for k, c in enumerate(constraints):
+        if not isinstance(c, tc.Tcalculus):
+            raise ValueError(f"constraint {k + 1} is not a Tcalculus expression")
+        if c.op == "iszero":
+            op1 = c.args[0]
+            Gc.append(op1)
+            v = Tvariable(f"nu{len(nus) + 1}__", op1.size)
+            nus.append(v)
+            code.declareSet(v, f"{classname}_set_{v.par}")
+        elif c.op == "ispositive":
+            op1 = c.args[0]
+            Fc.append(op1)
+            v = Tvariable(f"lambda{len(lambdas) + 1}__", op1.size)
+            lambdas.append(v)
+            code.declareSet(v, f"{classname}_set_{v.par}")
+        else:
+            raise ValueError(f"constraint of type '{c.op}' not implemented")
+    return packExpressions(Gc), packExpressions(Fc), nus, lambdas
+
+
+class SolverSpec:
+    """Everything a back-end needs: the tape, the solver ``#define`` block
+    (cmex2optimizeCS.m:303-331) and the class template (names, sizes)."""
+
+    def __init__(self, classname, tape, defines, parameters, variables, outputs, folder):
+        self.classname = classname
+        self.tape = tape
+        self.defines = defines
+        self.parameters = parameters      # [(name, size)]
+        self.variables = variables        # [(name, size)]
+        self.outputs = outputs            # [(name, size)]
+        self.folder = folder
+
+    def build(self, **kw):
+        from .hip_emitter import build_class
+        return build_class(self, **kw)
+
+    def load(self, **kw):
+        from .runtime import load_class
+        return load_class(self, **kw)
+
+
+def cmex2optimizeCS(*, classname, objective, optimizationVariables, constraints=(),
+                    parameters=(), outputExpressions=(), outputNames=None, folder=".",
+                    gradTolerance=1e-4, equalTolerance=1e-4, desiredDualityGap=1e-5,
+                    scaleInequalities=True, scaleCost=0.0, scaleEqualities=False,
+                    muFactorAggressive=0.2, muFactorConservative=0.95, skipAffine=True,
+                    delta=3, alphaMin=1e-7, alphaMax=1.0, coupledAlphas=True,
+                    addEye2Hessian=True, adjustAddEye2Hessian=True, useInertia=False,
+                    addEye2HessianUtolerance=1e-6, smallerNewtonMatrix=False, useLDL=True,
+                    useUmfpack=False, allowSave=False, solverVerboseLevel=0, **ignored):
+    """Generate an interior-point solver for ``min objective s.t. constraints``.
+
+    Unsupported reference options raise, exactly as ipmPD_CStimesLambda.m:31-48 does."""
+    if not skipAffine:
+        raise NotImplementedError("skipAffine=false not implemented (ipmPD_CStimesLambda.m:37-39)")
+    if smallerNewtonMatrix:
+        raise NotImplementedError("smallerNewtonMatrix=true not implemented (ipmPD_CStimesLambda.m:34-36)")
+    if not useLDL or useUmfpack:
+        raise NotImplementedError("only the LDL path is implemented (ipmPD_CStimesLambda.m:40-45)")
+    if allowSave:
+        raise NotImplementedError("allowSave is not supported by the HIP back-end")
+    classname = re.sub(r"[-+]", "_", classname)
+    objective = tc.toT(objective)
+    if objective.size != ():
+        raise ValueError(f"Minimization criterion must be scalar (not {list(objective.size)})")
+    optimizationVariables = list(optimizationVariables)
+    parameters = list(parameters)
+    for v in optimizationVariables:
+        if not isinstance(v, tc.Tcalculus) or v.op != "variable":
+            raise ValueError("all optimizationVariables must be of the type 'variable'")
+        for p in parameters:
+            if p.par == v.par:
+                raise ValueError(f"optimization variable '{v.par}' cannot also be a parameter")
+    outputExpressions = [tc.toT(o) for o in outputExpressions]
+    if outputNames is None:
+        outputNames = [o.par if o.op == "variable" else f"y{k + 1}"
+                       for k, o in enumerate(outputExpressions)]
+
+    code = CSparse()
+    for p in parameters:
+        code.declareSet(p, f"{classname}_set_{p.par}", external=True)
+    for v in optimizationVariables:
+        code.declareSet(v, f"{classname}_set_{v.par}", external=True)
+    G, F, nus, lambdas = parseConstraints(code, classname, list(constraints))
+    u, where, objective_u, outs_u, F, G = packVariables(
+        optimizationVariables, "x_", objective, outputExpressions, F, G)
+    outputExpressions = list(outs_u)
+    u0 = packExpressions(optimizationVariables)
+    code.declareCopy(u, u0, "initPrimal__")
+    nG = G.size[0]
+    nF = F.size[0]
+    if nG > 0:
+        nu, _, outputExpressions = packVariables(nus, "nu_", outputExpressions)
+        outputExpressions = list(outputExpressions)
+    else:
+        nu = Tzeros((0,))
+    if nF > 0:
+        lam, _, outputExpressions = packVariables(lambdas, "lambda_", outputExpressions)
+        outputExpressions = list(outputExpressions)
+    else:
+        lam = Tzeros((0,))
+    Tout = ipmPD_CStimesLambda(code, u, objective_u, F, G, lam, nu,
+                               addEye2Hessian=addEye2Hessian, scaleCost=scaleCost,
+                               scaleInequalities=scaleInequalities, classname=classname)
+    # outputs may refer to internal quantities through '<field>_' variables (cmex2optimizeCS.m:265-271)
+    for fn, val in Tout.items():
+        ph = Tvariable(fn + "_", val.size)
+        outputExpressions = [substitute(o, ph, val) for o in outputExpressions]
+    code.declareGet(outputExpressions, f"{classname}_getOutputs", list(outputNames))
+
+    defines = dict(
+        nU=u.size[0], nG=nG, nF=nF,
+        gradTolerance=float(gradTolerance), addEye2HessianUtolerance=float(addEye2HessianUtolerance),
+        equalTolerance=float(equalTolerance), desiredDualityGap=float(desiredDualityGap),
+        scaleCost=int(scaleCost != 0), scaleInequalities=int(bool(scaleInequalities)),
+        scaleEqualities=int(bool(scaleEqualities)), alphaMin=float(alphaMin), alphaMax=float(alphaMax),
+        coupledAlphas=int(bool(coupledAlphas)), setAddEye2Hessian=int(bool(addEye2Hessian)),
+        adjustAddEye2Hessian=int(bool(adjustAddEye2Hessian)), useInertia=int(bool(useInertia)),
+        muFactorAggressive=float(muFactorAggressive), muFactorConservative=float(muFactorConservative),
+        delta=int(delta), skipAffine=1, smallerNewtonMatrix=0, useLDL=1, useUmfpack=0, allowSave=0,
+        debugConvergence=0, profiling=0, verboseLevel=int(solverVerboseLevel))
+    tape = code.compile(defines)
+    spec = SolverSpec(classname, tape, defines,
+                      [(p.par, p.size) for p in parameters],
+                      [(v.par, v.size) for v in optimizationVariables],
+                      [(nm, o.size) for nm, o in zip(outputNames, outputExpressions)], folder)
+    spec.code = code
+    spec.Tout = Tout
+    return spec

@@ -1,0 +1,162 @@
+"""Symbolic assembly of the primal-dual interior-point step (code-generation time).
+
+Restates /root/reference/lib/ipmPD_CStimesLambda.m (the variant ``cmex2optimizeCS``
+hard-selects, cmex2optimizeCS.m:83-95) for ``packOptimizationVariables=true``:
+Lagrangian, gradient, Hessian, KKT matrix ``WW``, right-hand side ``b``,
+``dx=ldl(WW)\\b`` and the multiplicative-lambda update, registered on a
+:class:`~tenscalc_amd.csparse.CSparse` object under the entry-point names the Newton
+loop calls (``lib/ipmPD_CSsolver.c:28-51``).
+"""
+from __future__ import annotations
+
+from . import tcalculus as tc
+from .tcalculus import (Teye, Tones, Tvariable, Tzeros, cat, clp, compose, diag, full,
+                        gradient, hessian, ldl, ldl_d, ldl_l, mldivide, norminf, plus,
+                        rdivide, substitute, tabs, times, tmin, tprod, transpose, tsum)
+
+
+def ipmPD_CStimesLambda(code, u, f, F, G, lam, nu, *, addEye2Hessian=True, scaleCost=0.0,
+                        scaleInequalities=True, classname="cls"):
+    """Register every tape entry point of the IPM on ``code``; returns the named
+    expressions (``u, F, G, nu, lambda, Lf_u, Lf_uu, Hess, dHess, lHess, b, dx, mu``)."""
+    out = {}
+    nU = u.size[0]
+    nG = G.size[0] if G.ndim else 0
+    nF = F.size[0] if F.ndim else 0
+
+    # -- scaling (ipmPD_CStimesLambda.m:86-103) --------------------------------------
+    if nF > 0 and scaleInequalities:
+        scale4Ineq = Tvariable("scale4Ineq__", F.size)
+        code.declareCopy(scale4Ineq, tabs(rdivide(1.0, F)), "scaleIneq__")
+        F = times(scale4Ineq, F)
+    if scaleCost > 0:
+        scale4Cost = Tvariable("scale4Cost__", ())
+        code.declareCopy(scale4Cost, tabs(rdivide(float(scaleCost), f)), "scaleCost__")
+        f = scale4Cost * f
+        code.declareGet(scale4Cost, "getScale4Cost__")
+    out["u"], out["F"], out["G"], out["nu"], out["lambda"] = u, F, G, nu, lam
+
+    # -- matrices used to modify the Hessian's inertia (:105-116) ------------------------
+    if addEye2Hessian:
+        addEye2HessianU = Tvariable("addEye2HessianU__", ())
+        addEye2HessianEq = Tvariable("addEye2HessianEq__", ())
+        code.declareSet(addEye2HessianU, "setAddEye2HessianU__")
+        code.declareSet(addEye2HessianEq, "setAddEye2HessianEq__")
+    else:
+        addEye2HessianU = Tzeros(())
+        addEye2HessianEq = Tzeros(())
+    out["addEye2HessianU"], out["addEye2HessianEq"] = addEye2HessianU, addEye2HessianEq
+
+    # -- cost (:121) -------------------------------------------------------------------------
+    code.declareGet(f, "getJ__")
+
+    # -- Lagrangian and derivatives (:124-187) ---------------------------------------------------
+    f_u = gradient(f, u)
+    Lf = f
+    if nF > 0:
+        F_u = gradient(F, u)
+        gap = tprod(lam, (-1,), F, (-1,))
+        Lf = Lf - gap
+    else:
+        F = Tzeros((0,))
+        F_u = Tzeros((0, nU))
+        gap = Tzeros(())
+    if nG > 0:
+        G_u = gradient(G, u)
+        Lf = Lf + tprod(nu, (-1,), G, (-1,))
+    else:
+        G = Tzeros((0,))
+        G_u = Tzeros((0, nU))
+    Lf_uu, Lf_u = hessian(Lf, u)
+    out["Lf_u"], out["Lf_uu"] = Lf_u, Lf_uu
+    code.declareGet(Lf_u, "getGrad__")
+    code.declareGet(norminf(Lf_u), "getNorminf_Grad__")
+
+    # -- barrier variable (:189-205) ------------------------------------------------------------
+    if nF > 0:
+        mu = Tvariable("mu__", ())
+        muOnes = tc.expand(mu, (nF,))
+        code.declareSet(mu, "setMu__")
+        code.declareCopy(lam, rdivide(muOnes, F), "initDualIneq__")
+        code.declareGet([gap, tmin(F, 1), tmin(lam, 1)], "getGapMinFMinLambda__")
+    else:
+        mu = Tzeros(())
+        muOnes = Tzeros((0,))
+    out["mu"] = mu
+
+    if nG > 0:
+        # automatic initialisation of nu (:207-221): simple and least-squares versions
+        code.declareCopy(nu, Tones((nG,)), "initDualEq__")
+        WW0 = cat(1, cat(2, Teye((nU, nU)), transpose(G_u)),
+                  cat(2, G_u, -(addEye2HessianEq * Teye((nG, nG)))))
+        factor_ww0 = ldl(WW0, classname + "_WW0")
+        b0 = cat(1, (transpose(F_u) * lam if nF > 0 else Tzeros((nU,))) - f_u, Tzeros((nG,)))
+        wnu0 = full(mldivide(factor_ww0, b0))
+        code.declareCopy(nu, wnu0[nU:nU + nG], "initDualEqX__")
+        code.declareGet(norminf(G), "getNorminf_G__")
+
+    # -- step sizes (:223-229) -----------------------------------------------------------------------
+    alphaPrimal = Tvariable("alphaPrimal__", ())
+    code.declareSet(alphaPrimal, "setAlphaPrimal__")
+    alphaDualEq = Tvariable("alphaDualEq__", ())
+    code.declareSet(alphaDualEq, "setAlphaDualEq__")
+    alphaDualIneq = Tvariable("alphaDualIneq__", ())
+    code.declareSet(alphaDualIneq, "setAlphaDualIneq__")
+
+    # -- Newton step (:234-258) --------------------------------------------------------------------
+    WW11 = Lf_uu + addEye2HessianU * Teye((nU, nU))
+    rows = [[WW11], [], []]
+    if nG > 0:
+        rows[0].append(transpose(G_u))
+        rows[1] = [G_u, -(addEye2HessianEq * Teye((nG, nG)))]
+    if nF > 0:
+        rows[0].append(-(transpose(F_u) * diag(lam)))
+        if nG > 0:
+            rows[1].append(Tzeros((nG, nF)))
+        rows[2] = [-(diag(lam) * F_u)]
+        if nG > 0:
+            rows[2].append(Tzeros((nF, nG)))
+        rows[2].append(-diag(times(F, lam)))
+    WW = cat(1, *[cat(2, *r) for r in rows if r])
+    out["Hess"] = WW
+    factor_ww = ldl(WW, classname + "_WW")
+    out["dHess"] = ldl_d(factor_ww)
+    out["lHess"] = ldl_l(factor_ww)
+    code.declareGet([tsum(compose(out["dHess"], "heaviside")),
+                     tsum(compose(-out["dHess"], "heaviside"))], "getHessInertia__")
+
+    bparts = [-Lf_u]
+    if nG > 0:
+        bparts.append(-G)
+    if nF > 0:
+        bparts.append(times(lam, F) - muOnes)
+    b = cat(1, *bparts)
+    dx = mldivide(factor_ww, b)
+    dx = code.declareAlias(dx, "dx__")
+    code.declareGet([norminf(WW * dx - b)], "getDirectionError__")
+
+    # -- updates (:260-281) ---------------------------------------------------------------------------
+    dU = dx[0:nU]
+    newU = u + alphaPrimal * dU
+    if nG > 0:
+        dNu = dx[nU:nU + nG]
+        newNu = nu + alphaDualEq * dNu
+    curvature = dU * (WW11 * dU)
+    code.declareGet(curvature, "getCurvature__")
+    dsts, srcs = [u], [newU]
+    if nG > 0:
+        dsts.append(nu)
+        srcs.append(newNu)
+    if nF > 0:
+        dLambda = dx[nU + nG:nU + nG + nF]
+        newLambda = times(lam, Tones((nF,)) + alphaDualIneq * dLambda)
+        maxAlphaPrimal = clp(F, F_u * dU)
+        maxAlphaDualIneq = clp(Tones((nF,)), dLambda)
+        code.declareGet([maxAlphaPrimal, maxAlphaDualIneq], "getMaxAlphas_s__")
+        newF = substitute(F, u, newU)
+        code.declareGet(tmin(newF, 1), "getMinF_s__")
+        dsts.append(lam)
+        srcs.append(newLambda)
+    code.declareCopy(dsts, srcs, "updatePrimalDual__")
+    out["b"], out["dx"] = b, dx
+    return out

@@ -1,0 +1,3 @@
+"""Problem statements of the BASELINE configs, written against the
+reference's own example scripts."""
+from .sls import sls, sls_data  # noqa: F401
