@@ -1,0 +1,180 @@
+#!/usr/bin/env python3
+"""Headline benchmark: IPM solves/sec, sls N=100 n=8, batch 65536 per GPU (BASELINE.json configs[1]).
+
+    python bench.py --gpus N --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+        --master-port P bench.py --gpus N --steps K --warmup W
+
+A "step" is one pass of the hot path (whole-batch interior-point solve, one kernel launch) over one
+batch of synthetic problem instances already resident in HBM in structure-of-arrays layout.  The
+batch shards embarrassingly: every rank owns B instances on its own GPU (weak scaling) and the only
+collective is the gather of results (outputs + status) over RCCL, included in the timed region for
+N>1.  Rank 0 prints ONE JSON line (see DESIGN.md "Measurement" for the roofline arithmetic).
+"""
+import argparse
+import ctypes
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+ALGO_BYTES_PER_SOLVE = 8 * (800 + 100 + 8) + 8 * (1 + 8) + 8   # 7344 B
+HBM_PEAK_GBPS = 8000.0                                           # MI355X_MICROARCH.md chip table
+
+
+class _DevArray:
+    """zero-copy view of handle-owned device memory for torch (cuda array interface v2)"""
+
+    def __init__(self, ptr, shape, typestr):
+        self.__cuda_array_interface__ = dict(shape=tuple(shape), typestr=typestr, data=(int(ptr), False),
+                                             version=2, strides=None)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--batch", type=int, default=65536, help="instances per GPU")
+    ap.add_argument("--variant", default=os.environ.get("TC_BENCH_VARIANT", "strict"), choices=["strict", "fast"])
+    ap.add_argument("--cpu-sample", type=int, default=int(os.environ.get("TC_CPU_SAMPLE", "40000")))
+    ap.add_argument("--no-cpu", action="store_true")
+    args = ap.parse_args()
+
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group(backend="nccl")   # RCCL on ROCm
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+
+    import __graft_entry__ as g
+    from tenscalc_amd.problems.sls import SOLVE_ARGS, sls
+    from tenscalc_amd.runtime import LAYOUT_BATCH_MINOR, HipSolver
+    spec = sls(folder=g.GENERATED)
+    kw = dict(fp_contract="off", tag="strict") if args.variant == "strict" else dict(fp_contract="fast")
+    if rank == 0:
+        so = spec.build(**kw)
+    if world > 1:
+        dist.barrier()
+    so = spec.build(**kw)
+
+    B = args.batch
+    gen = torch.Generator(device=dev).manual_seed(1234 + rank)
+    A = torch.rand((800, B), generator=gen, device=dev, dtype=torch.float64)      # [N*n][B] column-major A per instance
+    b = torch.rand((100, B), generator=gen, device=dev, dtype=torch.float64)
+    x0 = .02 * torch.rand((8, B), generator=gen, device=dev, dtype=torch.float64)
+    obj = HipSolver(so, B=B, device=local)
+    stream = torch.cuda.current_stream().cuda_stream
+    for nm, t in (("A", A), ("b", b), ("x", x0)):
+        obj.set_device(nm, t, LAYOUT_BATCH_MINOR, stream=stream)
+    torch.cuda.synchronize()
+    optr, sptr, iptr = obj.device_views()
+    O = torch.as_tensor(_DevArray(optr, (9, B), "<f8"), device=dev)
+    ST = torch.as_tensor(_DevArray(sptr, (B,), "<i4"), device=dev)
+    IT = torch.as_tensor(_DevArray(iptr, (B,), "<i4"), device=dev)
+    gathered = torch.empty((world, 10, B), dtype=torch.float64, device=dev) if world > 1 else None
+
+    def step():
+        obj.solve_async(SOLVE_ARGS["mu0"], SOLVE_ARGS["maxIter"], SOLVE_ARGS["addEye2Hessian"], stream=stream)
+        if world > 1:   # gather results (J, x, status) on every rank -- the path's only exchange
+            pack = torch.cat([O, ST.to(torch.float64)[None]], 0)
+            dist.all_gather_into_tensor(gathered.view(world * 10, B), pack)
+
+    for _ in range(args.warmup):
+        step()
+    # --- timed region: barrier + synchronize on both sides, exactly K steps
+    kern_ms = []
+    evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for k in range(args.steps):
+        evs[k][0].record()
+        obj.solve_async(SOLVE_ARGS["mu0"], SOLVE_ARGS["maxIter"], SOLVE_ARGS["addEye2Hessian"], stream=stream)
+        evs[k][1].record()
+        if world > 1:
+            pack = torch.cat([O, ST.to(torch.float64)[None]], 0)
+            dist.all_gather_into_tensor(gathered.view(world * 10, B), pack)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    elapsed = time.perf_counter() - t0
+    kern_ms = [a.elapsed_time(b_) for a, b_ in evs]          # events on the launch stream
+    el = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+    ok = (ST == 0).sum().to(torch.float64).reshape(1)
+    if world > 1:
+        dist.all_reduce(el, op=dist.ReduceOp.MAX)
+        dist.all_reduce(ok, op=dist.ReduceOp.SUM)
+    elapsed = float(el.item())
+    solved_per_step = float(ok.item())                        # only status==0 instances count
+    value = solved_per_step * args.steps / elapsed
+
+    out = None
+    if rank == 0:
+        it = IT.cpu().numpy()
+        kavg = float(np.mean(kern_ms)) * 1e-3
+        achieved = ALGO_BYTES_PER_SOLVE * B / kavg / 1e9
+        out = {
+            "metric": "IPM solves/sec (whole node), sls N=100 n=8 batch",
+            "value": value, "unit": "solves/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "config": {"workload": "sls box-constrained LS N=100 n=8, batch=%d random (A,b) per GPU, fp64 "
+                                   "(BASELINE.json configs[1])" % B,
+                       "batch_per_gpu": B, "mu0": SOLVE_ARGS["mu0"], "maxIter": SOLVE_ARGS["maxIter"],
+                       "variant": args.variant, "solved_fraction": solved_per_step / (B * world),
+                       "iter_median": float(np.median(it)), "iter_max": int(it.max()),
+                       "sharding": "independent instances per rank, RCCL all_gather of results only"},
+            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBPS, "traffic": None,
+                         "kernel": "tc_solve_kernel", "kernel_ms_avg": kavg * 1e3,
+                         "algorithmic_bytes_per_solve": ALGO_BYTES_PER_SOLVE},
+        }
+        if not args.no_cpu and world >= 1:
+            out["cpu_baseline"] = cpu_baseline(spec, A, b, x0, args.cpu_sample, SOLVE_ARGS)
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+    obj.close()
+
+
+def cpu_baseline(spec, A, b, x0, sample, solve_args):
+    """The oracle (CPU restatement of the reference path, kind "port") timed on ONE host core over
+    the first `sample` instances of the same workload."""
+    import numpy as np
+    from oracle.tc_oracle import Oracle
+    import __graft_entry__ as g
+    tape = os.path.join(g.GENERATED, "@" + spec.classname, spec.classname + ".tape")
+    o = Oracle(tape)
+    c = spec.classname
+    n = min(sample, A.shape[1])
+    Ah = np.ascontiguousarray(A[:, :n].t().cpu().numpy())
+    bh = np.ascontiguousarray(b[:, :n].t().cpu().numpy())
+    xh = np.ascontiguousarray(x0[:, :n].t().cpu().numpy())
+    o.solve_batch({c + "_set_A": Ah[:64], c + "_set_b": bh[:64], c + "_set_x": xh[:64]}, c + "_getOutputs", 64,
+                  mu0=solve_args["mu0"], maxIter=solve_args["maxIter"])          # warm-up
+    t0 = time.perf_counter()
+    out, st, it = o.solve_batch({c + "_set_A": Ah, c + "_set_b": bh, c + "_set_x": xh}, c + "_getOutputs", n,
+                                mu0=solve_args["mu0"], maxIter=solve_args["maxIter"])
+    dt = time.perf_counter() - t0
+    return {"value": float((st == 0).sum()) / dt, "unit": "solves/s", "cores": 1, "kind": "port",
+            "sample": "first %d instances of the benchmark batch, oracle/tc_oracle.c (tape interpreter + "
+                      "restated ipmPD_CSsolver loop, gcc -O1), sequential on 1 of %d host cores, %.1f s"
+                      % (n, os.cpu_count(), dt),
+            "us_per_solve": dt / n * 1e6}
+
+
+if __name__ == "__main__":
+    main()

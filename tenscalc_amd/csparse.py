@@ -82,11 +82,12 @@ def _groups(sorted_keys):
     return brk.astype(np.int64), cnt.astype(np.int64)
 
 
-def min_degree_order(n, rows, cols):
+def min_degree_order(n, rows, cols, stages=None):
     """Greedy minimum-degree elimination order of the symmetric pattern (rows,cols).
     Stands in for MATLAB ``symamd(A,[1000,0])`` at sparsity_ldl.m:91; any valid order
     gives the same solution up to rounding (SURVEY.md 7 hard part 1).  Ties are broken
-    by lowest index so the order is deterministic."""
+    by lowest index so the order is deterministic.  With ``stages`` every node of stage s
+    is eliminated before any node of stage s+1."""
     adj = [set() for _ in range(n)]
     for r, c in zip(rows, cols):
         r, c = int(r), int(c)
@@ -94,12 +95,13 @@ def min_degree_order(n, rows, cols):
             adj[r].add(c)
             adj[c].add(r)
     import heapq
-    heap = [(len(adj[i]), i) for i in range(n)]
+    stg = [0] * n if stages is None else [int(s) for s in stages]
+    heap = [(stg[i], len(adj[i]), i) for i in range(n)]
     heapq.heapify(heap)
     done = [False] * n
     order = []
     while heap:
-        d, i = heapq.heappop(heap)
+        _, d, i = heapq.heappop(heap)
         if done[i] or d != len(adj[i]):
             continue
         done[i] = True
@@ -113,7 +115,7 @@ def min_degree_order(n, rows, cols):
             new.discard(a)
             if new:
                 adj[a] |= new
-            heapq.heappush(heap, (len(adj[a]), a))
+            heapq.heappush(heap, (stg[a], len(adj[a]), a))
         adj[i] = set()
     return np.array(order, dtype=np.int64)
 
@@ -580,7 +582,8 @@ class CSparse:
         N = n.size[0]
         ent = {(int(r), int(c)): int(i) for (r, c), i in zip(subs, ins)}
         nonsym = sum(1 for (r, c), i in ent.items() if ent.get((c, r)) != i)
-        p = min_degree_order(N, subs[:, 0], subs[:, 1])
+        tag, stages = n.par
+        p = min_degree_order(N, subs[:, 0], subs[:, 1], stages)
         pinv = np.empty(N, dtype=np.int64)
         pinv[p] = np.arange(N)
         # permuted lower triangle (row>col) and diagonal: Xp(r,c)=A(p[r],p[c])
@@ -646,7 +649,7 @@ class CSparse:
         self.ldl_perm[n.idx] = p
         nnzL = sum(len(x) for x in Lrow)
         self.ldl_stats.append(dict(n=N, nnzA=len(ent), nonsym=nonsym, nnzL=nnzL,
-                                   new_instructions=len(t) - n0, tag=n.par))
+                                   new_instructions=len(t) - n0, tag=tag))
         subs = np.array(S, dtype=np.int64).reshape(-1, 2)
         ins = np.array(Ins, dtype=np.int64)
         return _sort_cm(subs, ins, n.size)

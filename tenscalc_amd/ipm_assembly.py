@@ -89,7 +89,7 @@ def ipmPD_CStimesLambda(code, u, f, F, G, lam, nu, *, addEye2Hessian=True, scale
         code.declareCopy(nu, Tones((nG,)), "initDualEq__")
         WW0 = cat(1, cat(2, Teye((nU, nU)), transpose(G_u)),
                   cat(2, G_u, -(addEye2HessianEq * Teye((nG, nG)))))
-        factor_ww0 = ldl(WW0, classname + "_WW0")
+        factor_ww0 = ldl(WW0, classname + "_WW0", stages=[0] * nU + [1] * nG)
         b0 = cat(1, (transpose(F_u) * lam if nF > 0 else Tzeros((nU,))) - f_u, Tzeros((nG,)))
         wnu0 = full(mldivide(factor_ww0, b0))
         code.declareCopy(nu, wnu0[nU:nU + nG], "initDualEqX__")
@@ -119,7 +119,9 @@ def ipmPD_CStimesLambda(code, u, f, F, G, lam, nu, *, addEye2Hessian=True, scale
         rows[2].append(-diag(times(F, lam)))
     WW = cat(1, *[cat(2, *r) for r in rows if r])
     out["Hess"] = WW
-    factor_ww = ldl(WW, classname + "_WW")
+    # elimination order: fill-reducing within {primal, inequality duals}, equality duals last so
+    # their -addEye2HessianEq pivots are never used before the primal block they couple
+    factor_ww = ldl(WW, classname + "_WW", stages=[0] * nU + [1] * nG + [0] * nF)
     out["dHess"] = ldl_d(factor_ww)
     out["lHess"] = ldl_l(factor_ww)
     code.declareGet([tsum(compose(out["dHess"], "heaviside")),

@@ -730,13 +730,19 @@ def full(x):
 # ------------------------------------------------------------------------------
 # factorizations
 # ------------------------------------------------------------------------------
-def ldl(A, tag=""):
+def ldl(A, tag="", stages=None):
     """Symbolic LDL' with a fixed (codegen-time) elimination order
-    (Tcalculus.m:1394-1486, @csparse/sparsity_ldl.m)."""
+    (Tcalculus.m:1394-1486, @csparse/sparsity_ldl.m).  ``stages`` (one int per row) constrains
+    the fill-reducing order: all rows of stage s are eliminated before any row of stage s+1
+    (used to keep the tiny -eps*I pivots of equality duals behind the primal block)."""
     A = toT(A)
     if A.ndim != 2 or A.size[0] != A.size[1]:
         raise ValueError("ldl: needs a square matrix")
-    return Tcalculus.make("ldl", A.size, (A,), str(tag))
+    if stages is not None:
+        stages = tuple(int(s) for s in stages)
+        if len(stages) != A.size[0]:
+            raise ValueError("ldl: one stage per row expected")
+    return Tcalculus.make("ldl", A.size, (A,), (str(tag), stages))
 
 
 def ldl_d(f):
@@ -992,7 +998,7 @@ def _rebuild(f, a):
     if op == "full":
         return full(a[0])
     if op == "ldl":
-        return ldl(a[0], f.par)
+        return ldl(a[0], f.par[0], f.par[1])
     if op == "ldl_d":
         return ldl_d(a[0])
     if op == "ldl_l":

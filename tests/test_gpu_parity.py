@@ -1,0 +1,219 @@
+"""GPU parity tests proper: the HIP path, called through the C-ABI, against the CPU oracle on the
+same seeded inputs, against the committed golden vectors, and -- at BASELINE's full batch --
+through size-independent properties.
+
+Tolerances.  `strict` build (-ffp-contract=off): the tape is evaluated in the reference's operand
+order with IEEE fp64 +,-,*,/ so every output must be BIT-IDENTICAL to the oracle, including
+status and iteration count.  `fast` build (FMA contraction on): not bit-identical; a Newton
+line-search decision can flip on a 1e-17 residue (see tests/test_oracle_sls.py), so the stated
+tolerance is the solver's own: same status, |iter difference| <= 2, |J-J_ref| <= 1e-7*max(1,|J|), |x-x_ref| <=
+5e-6, and -- the north-star criterion -- KKT residuals (|grad|_inf, duality gap) within the
+solver tolerances and within 1e-10 of the oracle's when the iteration counts agree.
+"""
+import os
+
+import numpy as np
+import pytest
+
+from tenscalc_amd.problems.sls import SOLVE_ARGS, sls_batch, sls_data
+
+pytestmark = pytest.mark.gpu
+GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "sls_N100_n8.npz")
+
+
+@pytest.fixture(scope="module")
+def libs():
+    import __graft_entry__ as g
+    return g.build()
+
+
+def _load(so, B):
+    from tenscalc_amd.runtime import HipSolver
+    return HipSolver(so, B=B, device=0)
+
+
+def _set(obj, A, b, x0):
+    obj.setP_A(np.ascontiguousarray(np.transpose(A, (0, 2, 1))))   # [B,n,N] C-order == MATLAB [N,n,B]
+    obj.setP_b(b)
+    obj.setV_x(x0)
+
+
+def _oracle_batch(spec, tape_path, A, b, x0, **kw):
+    from oracle.tc_oracle import Oracle
+    o = Oracle(tape_path)
+    c = spec.classname
+    B = A.shape[0]
+    args = dict(mu0=SOLVE_ARGS["mu0"], maxIter=SOLVE_ARGS["maxIter"])
+    args.update(kw)
+    return o.solve_batch({c + "_set_A": np.transpose(A, (0, 2, 1)).reshape(B, -1), c + "_set_b": b,
+                          c + "_set_x": x0}, c + "_getOutputs", B, **args)
+
+
+def test_strict_bit_exact_vs_oracle(libs, sls_spec, sls_tape_path):
+    B = 1000                               # ragged: not a multiple of the 64-wide wavefront
+    A, b, x0 = sls_batch(B, seed0=1000)
+    obj = _load(libs["sls_strict"], B)
+    _set(obj, A, b, x0)
+    st, it, t = obj.solve(**SOLVE_ARGS)
+    J, x = obj.getOutputs()
+    ref, rst, rit = _oracle_batch(sls_spec, sls_tape_path, A, b, x0)
+    assert np.array_equal(st, rst) and np.array_equal(it, rit)
+    assert np.array_equal(J.reshape(B), ref[:, 0]) and np.array_equal(x.reshape(B, 8), ref[:, 1:])
+    assert (st == 0).all()
+
+
+def test_strict_golden_vectors(libs):
+    g = np.load(GOLD)
+    B = len(g["seeds"])
+    A, b, x0 = sls_batch(B, seed0=int(g["seeds"][0]))
+    obj = _load(libs["sls_strict"], B)
+    _set(obj, A, b, x0)
+    st, it, _ = obj.solve(**SOLVE_ARGS)
+    J, x = obj.getOutputs()
+    assert np.array_equal(st, g["status"]) and np.array_equal(it, g["iter"])
+    assert np.array_equal(J.reshape(B), g["J"]) and np.array_equal(x.reshape(B, 8), g["x"])
+
+
+def test_strict_tape_probes_golden(libs):
+    """tape evaluation alone (gradient, Hessian, KKT, LDL, solves) right after initialisation"""
+    g = np.load(GOLD)
+    B = len(g["seeds"])
+    A, b, x0 = sls_batch(B, seed0=int(g["seeds"][0]))
+    obj = _load(libs["sls_strict"], B)
+    _set(obj, A, b, x0)
+    for p in ["getJ__", "getNorminf_Grad__", "getGapMinFMinLambda__", "getCurvature__",
+              "getDirectionError__", "getMaxAlphas_s__", "getGrad__"]:
+        got = obj.probe(p, mu0=SOLVE_ARGS["mu0"])
+        assert np.array_equal(got, g["probe_" + p].reshape(B, -1)), p
+
+
+def test_strict_edge_cases_status_bits(libs, sls_spec, sls_tape_path):
+    """maxIter exhaustion (status 8|...), NaN parameters (status 4), B=1, other mu0/addEye."""
+    B = 130
+    A, b, x0 = sls_batch(B, seed0=5000)
+    A[3] *= np.nan
+    b[5] *= 1e6
+    A[7] *= 0
+    x0[9] = .05 - 1e-13
+    for kw in [dict(mu0=1.0, maxIter=4), dict(mu0=1e-3, maxIter=30), dict(mu0=10.0, maxIter=60, addEye2Hessian=(1e-3, 1e-3))]:
+        obj = _load(libs["sls_strict"], B)
+        _set(obj, A, b, x0)
+        st, it, _ = obj.solve(**{**SOLVE_ARGS, **kw})
+        J, x = obj.getOutputs()
+        ref, rst, rit = _oracle_batch(sls_spec, sls_tape_path, A, b, x0, **kw)
+        assert np.array_equal(st, rst) and np.array_equal(it, rit), kw
+        assert np.array_equal(J.reshape(B), ref[:, 0], equal_nan=True)
+        assert np.array_equal(x.reshape(B, 8), ref[:, 1:], equal_nan=True)
+        assert st[3] == 4
+    one = _load(libs["sls_strict"], 1)
+    _set(one, A[:1], b[:1], x0[:1])
+    st, it, _ = one.solve(**SOLVE_ARGS)
+    ref, rst, rit = _oracle_batch(sls_spec, sls_tape_path, A[:1], b[:1], x0[:1])
+    assert st[0] == rst[0] and it[0] == rit[0] and np.array_equal(one.getOutputs()[1].reshape(1, 8), ref[:, 1:])
+
+
+def test_reference_c_surface_single_instance(libs, sls_spec, sls_tape_path):
+    """the reference's own C symbols (<cls>_set_*, ipmPD_CSsolver, <cls>_getOutputs) at B=1"""
+    import ctypes
+    L = ctypes.CDLL(libs["sls_strict"], mode=ctypes.RTLD_LOCAL)
+    c = sls_spec.classname
+    A, b, x0 = sls_data(11)
+    dp = ctypes.POINTER(ctypes.c_double)
+    Af = np.ascontiguousarray(A.reshape(-1, order="F"))
+    getattr(L, c + "_set_A")(Af.ctypes.data_as(dp))
+    getattr(L, c + "_set_b")(b.ctypes.data_as(dp))
+    getattr(L, c + "_set_x")(x0.ctypes.data_as(dp))
+    mu0, mi, si = ctypes.c_double(1.0), ctypes.c_int32(30), ctypes.c_int32(-1)
+    ae = (ctypes.c_double * 2)(1e-9, 1e-9)
+    st, it, tm = ctypes.c_int32(-1), ctypes.c_int32(-1), ctypes.c_double(0)
+    L.ipmPD_CSsolver(ctypes.byref(mu0), ctypes.byref(mi), ctypes.byref(si), ae, ctypes.byref(st),
+                     ctypes.byref(it), ctypes.byref(tm))
+    J = ctypes.c_double(0)
+    x = np.zeros(8)
+    getattr(L, c + "_getOutputs")(ctypes.byref(J), x.ctypes.data_as(dp))
+    ref, rst, rit = _oracle_batch(sls_spec, sls_tape_path, A[None], b[None], x0[None])
+    assert (st.value, it.value) == (rst[0], rit[0])
+    assert J.value == ref[0, 0] and np.array_equal(x, ref[0, 1:])
+
+
+def test_fast_build_within_stated_tolerance(libs, sls_spec, sls_tape_path):
+    B = 2048
+    A, b, x0 = sls_batch(B, seed0=20000)
+    obj = _load(libs["sls_fast"], B)
+    _set(obj, A, b, x0)
+    st, it, _ = obj.solve(**SOLVE_ARGS)
+    J, x = obj.getOutputs()
+    J, x = J.reshape(B), x.reshape(B, 8)
+    ref, rst, rit = _oracle_batch(sls_spec, sls_tape_path, A, b, x0)
+    assert np.array_equal(st, rst) and (st == 0).all()
+    assert np.abs(it - rit).max() <= 2
+    assert np.abs(J - ref[:, 0]).max() <= 1e-7
+    assert np.abs(x - ref[:, 1:]).max() <= 5e-6
+    same = it == rit
+    assert same.mean() > 0.8
+    # KKT residual of the returned point, recomputed on the host in fp64 (north star: within 1e-10
+    # of the reference's where the two took the same path)
+    def kkt(xv):
+        return np.einsum("bij,bi->bj", A, np.einsum("bij,bj->bi", A, xv) - b) * (2 / 100)
+    r_gpu, r_ref = kkt(x), kkt(ref[:, 1:])
+    assert np.abs(r_gpu - r_ref)[same].max() <= 1e-10
+    assert (x >= 0).all() and (x <= .05).all()
+
+
+def test_device_resident_inputs_both_layouts(libs, sls_spec, sls_tape_path):
+    import torch
+    B = 512
+    A, b, x0 = sls_batch(B, seed0=777)
+    ref, rst, rit = _oracle_batch(sls_spec, sls_tape_path, A, b, x0)
+    from tenscalc_amd.runtime import LAYOUT_BATCH_MINOR, LAYOUT_INSTANCE_MAJOR
+    Aim = torch.from_numpy(np.ascontiguousarray(np.transpose(A, (0, 2, 1)).reshape(B, 800))).cuda()
+    bim = torch.from_numpy(b).cuda()
+    xim = torch.from_numpy(x0).cuda()
+    for layout in (LAYOUT_INSTANCE_MAJOR, LAYOUT_BATCH_MINOR):
+        obj = _load(libs["sls_strict"], B)
+        tr = (lambda t: t) if layout == LAYOUT_INSTANCE_MAJOR else (lambda t: t.t().contiguous())
+        obj.set_device("A", tr(Aim), layout)
+        obj.set_device("b", tr(bim), layout)
+        obj.set_device("x", tr(xim), layout)
+        obj.synchronize()
+        st, it, _ = obj.solve(**SOLVE_ARGS)
+        J, x = obj.getOutputs()
+        assert np.array_equal(st, rst) and np.array_equal(it, rit)
+        assert np.array_equal(x.reshape(B, 8), ref[:, 1:])
+
+
+def test_full_batch_properties(libs):
+    """BASELINE config 2 size (B=65536): properties that need no CPU oracle -- every instance
+    converges, respects the box, satisfies the KKT tolerances, is invariant to where it sits in the
+    batch (permutation), and a second solve() reproduces the first bit-for-bit."""
+    import torch
+    B = 65536
+    g = torch.Generator(device="cuda").manual_seed(1)
+    A = torch.rand((800, B), generator=g, device="cuda", dtype=torch.float64)
+    b = torch.rand((100, B), generator=g, device="cuda", dtype=torch.float64)
+    x0 = .02 * torch.rand((8, B), generator=g, device="cuda", dtype=torch.float64)
+    from tenscalc_amd.runtime import LAYOUT_BATCH_MINOR
+    obj = _load(libs["sls_strict"], B)
+    for nm, t in (("A", A), ("b", b), ("x", x0)):
+        obj.set_device(nm, t, LAYOUT_BATCH_MINOR)
+    obj.synchronize()
+    st, it, t1 = obj.solve(**SOLVE_ARGS)
+    J, x = obj.getOutputs()
+    x = x.reshape(B, 8)
+    assert (st == 0).all() and it.min() >= 8 and it.max() <= 20
+    assert (x > 0).all() and (x < .05).all()
+    Ah = A.cpu().numpy().reshape(8, 100, B)            # [n][N][B]
+    r = np.einsum("jib,jb->ib", Ah, x.T) - b.cpu().numpy()
+    assert np.allclose(J.reshape(B), (r ** 2).sum(0) / 100, rtol=1e-12)
+    st2, it2, _ = obj.solve(**SOLVE_ARGS)
+    J2, x2 = obj.getOutputs()
+    assert np.array_equal(st, st2) and np.array_equal(it, it2) and np.array_equal(x2.reshape(B, 8), x)
+    perm = torch.randperm(B, generator=torch.Generator().manual_seed(2)).cuda()
+    obj2 = _load(libs["sls_strict"], B)
+    for nm, t in (("A", A), ("b", b), ("x", x0)):
+        obj2.set_device(nm, t[:, perm].contiguous(), LAYOUT_BATCH_MINOR)
+    obj2.synchronize()
+    st3, it3, _ = obj2.solve(**SOLVE_ARGS)
+    x3 = obj2.getOutputs()[1].reshape(B, 8)
+    p = perm.cpu().numpy()
+    assert np.array_equal(it3, it[p]) and np.array_equal(x3, x[p])
