@@ -62,6 +62,11 @@ def main():
     from tenscalc_amd.runtime import LAYOUT_BATCH_MINOR, HipSolver
     spec = sls(folder=g.GENERATED)
     kw = dict(fp_contract="off", tag="strict") if args.variant == "strict" else dict(fp_contract="fast")
+    if os.environ.get("TC_EXPERIMENT"):          # e.g. TC_EXPERIMENT="min_waves=2,block=256" (tuning runs)
+        for kv in os.environ["TC_EXPERIMENT"].split(","):
+            k_, v_ = kv.split("=")
+            kw[k_] = int(v_)
+        kw["tag"] = (kw.get("tag", "fast") + "_" + os.environ["TC_EXPERIMENT"].replace("=", "").replace(",", "_"))
     if rank == 0:
         so = spec.build(**kw)
     if world > 1:

@@ -59,96 +59,103 @@ def _lit(v):
     return "(" + s + ")" if v < 0 else s
 
 
-class Lowering:
-    """Storage classification + statement printer for one tape."""
+from .lowering import Family, Leaf, Lowering, Node  # noqa: E402
 
-    def __init__(self, tape):
-        T = self.T = tape
-        n = T.n
-        types, opStart, ops = T.types, T.opStart, T.ops
-        # who reads what -------------------------------------------------------------
-        self.external = np.zeros(n + 1, dtype=bool)
-        self.ext_index = np.full(n + 1, -1, dtype=np.int64)
-        self.inputs = []            # external sets in declaration order
-        off = 0
-        for e in T.sets:
-            if e["external"]:
-                self.external[e["ins"]] = True
-                self.ext_index[e["ins"]] = off + np.arange(len(e["ins"]))
-                self.inputs.append(dict(name=e["varname"], entry=e["name"], size=e["size"],
-                                        numel=len(e["ins"]), off=off))
-                off += len(e["ins"])
-        self.nExt = off
-        out_needed = np.zeros(n + 1, dtype=bool)   # read by a get / copy source
-        for e in T.gets:
-            for o in e["outputs"]:
-                out_needed[o["ins"]] = True
-        for e in T.copies:
-            out_needed[e["src"]] = True
-        # group-local: every reader is in the same group, and no entry point reads it
-        local = np.zeros(n + 1, dtype=bool)
-        grp = T.group
-        readers_other = np.zeros(n + 1, dtype=bool)
-        opl, ost = ops.tolist(), opStart.tolist()
-        for i in range(1, n + 1):
-            gi = grp[i]
-            if gi == 0:
-                continue
-            for j in opl[ost[i - 1]:ost[i]]:
-                if grp[j] != gi:
-                    readers_other[j] = True
-        for i in range(1, n + 1):
-            if grp[i] and not readers_other[i] and not out_needed[i]:
-                local[i] = True
-        self.local = local
-        # private slots: internal sets that someone reads + non-local computed values
-        read_any = np.zeros(n + 1, dtype=bool)
-        for i in range(1, n + 1):
-            if T.used[i]:
-                for j in opl[ost[i - 1]:ost[i]]:
-                    read_any[j] = True
-        read_any |= out_needed
-        pslot = np.full(n + 1, -1, dtype=np.int64)
-        k = 0
-        for i in range(1, n + 1):
-            if T.isset[i - 1]:
-                if not self.external[i] and read_any[i]:
-                    pslot[i] = k
-                    k += 1
-            elif grp[i] and not local[i]:
-                pslot[i] = k
-                k += 1
-        self.pslot = pslot
-        self.nPriv = k
 
-    # -- operand / destination text ---------------------------------------------------
-    def ref(self, i):
-        T = self.T
-        i = int(i)
-        if T.isload[i - 1]:
-            return _lit(T.pars[T.parStart[i - 1]])
-        if self.external[i]:
-            return f"SX({self.ext_index[i]})"
-        if self.local[i]:
-            return f"t{i}"
-        if self.pslot[i] < 0:
-            raise AssertionError(f"instruction {i} has no storage")
-        return f"MM({self.pslot[i]})"
+class Printer:
+    """Expression printer for one Lowering (semantics: instructionsTableUTHash.c:950-1599)."""
 
-    def assign(self, i, expr):
-        if self.local[i]:
-            return f"  const double t{i} = {expr};\n"
-        return f"  MM({self.pslot[i]}) = {expr};\n"
+    def __init__(self, L, roll=True):
+        self.L = L
+        self.roll = roll
 
-    def statement(self, i):
-        """HIP text computing instruction i (semantics: instructionsTableUTHash.c:950-1599)."""
-        typ, par, ops = self.T.instr(i)
-        r = [self.ref(o) for o in ops]
+    # leaf text ---------------------------------------------------------------------------------
+    @staticmethod
+    def leaf_text(lf, base=None, dc=0, dk=0):
+        if lf.kind == "lit":
+            return _lit(lf.val)
+        if lf.kind == "tmp":
+            return f"t{lf.idx}"
+        b = lf.idx if base is None else base
+        ix = str(b)
+        if dc:
+            ix += f"+{dc}*c_" if dc != 1 else "+c_"
+        if dk:
+            ix += f"+{dk}*k_" if dk != 1 else "+k_"
+        return f"SX({ix})" if lf.kind == "ext" else f"MM({ix})"
+
+    def expr(self, t, fam=None, pos=None):
+        """C expression of tree t.  fam: Family (leaf index = base+delta*c_) or None.
+        pos: running index into the flattened leaf list (list of one int)."""
+        if pos is None:
+            pos = [0]
+        L = self.L
+        base = fam.base if fam else None
+        delta = fam.delta if fam else None
+        # V2: long sums rolled over the term index k_
+        if self.roll and t.typ in (I.I_sumprod, I.I_plus_sqr) and all(isinstance(k, Leaf) for k in t.kids):
+            lb = base if fam else [k.idx for k in t.kids]
+            ld = delta if fam else [0] * len(t.kids)
+            p0 = pos[0] if fam else 0
+            tf = Lowering.term_family(t, lb, ld, p0)
+            if tf is not None:
+                pos[0] += len(t.kids)
+                return self._term_loop(t, tf)
+        r = []
+        for k in t.kids:
+            if isinstance(k, Leaf):
+                j = pos[0]
+                pos[0] += 1
+                r.append(self.leaf_text(k, base[j] if fam else None, delta[j] if fam else 0))
+            else:
+                r.append("(" + self.expr(k, fam, pos) + ")")
+        return self.op_text(t.typ, t.par, r)
+
+    def _term_loop(self, t, tf):
+        nf, ns, facs = tf
+
+        def term(kexpr):
+            fs = []
+            for kind, b0, dk, dc, l0 in facs:
+                if kind == "lit":
+                    fs.append(_lit(l0.val))
+                elif kind == "tmp":
+                    fs.append(f"t{l0.idx}")
+                else:
+                    ix = f"{b0}"
+                    if dc:
+                        ix += f"+{dc}*c_" if dc != 1 else "+c_"
+                    if dk:
+                        ix += f"+{dk}*({kexpr})" if dk != 1 else f"+({kexpr})"
+                    fs.append(f"SX({ix})" if kind == "ext" else f"MM({ix})")
+            if t.typ == I.I_plus_sqr:
+                return f"{fs[0]}*{fs[0]}"
+            return "*".join(fs)
+        # chunk boundaries: a new "m[r]+=" statement every MAX_TERMS_PERLINE factors (:1003-1012)
+        bounds, nSums, k0 = [], 0, 0
+        if t.typ == I.I_sumprod:
+            for k in range(ns):
+                if k + 1 < ns:
+                    nSums += nf
+                    if nSums >= MAX_TERMS_PERLINE:
+                        bounds.append((k0, k + 1))
+                        k0, nSums = k + 1, 0
+        bounds.append((k0, ns))
+        s = "({ double tot_ = 0, ln_;"
+        for q, (a, b) in enumerate(bounds):
+            s += f" ln_ = {term(str(a))};"
+            if b - a > 1:
+                s += f" _Pragma(\"unroll 4\") for (int k_ = {a + 1}; k_ < {b}; k_++) ln_ = ln_ + {term('k_')};"
+            s += " tot_ = ln_;" if q == 0 else " tot_ = tot_ + ln_;"
+        return s + " tot_; })"
+
+    @staticmethod
+    def op_text(typ, par, r):
         if typ == I.I_sum:
             s = ("+" if par[0] > 0 else "-") + r[0]
             for p, x in zip(par[1:], r[1:]):
                 s += ("+" if p > 0 else "-") + x
-            return self.assign(i, s)
+            return s
         if typ == I.I_sumprod:
             nf, ns = int(par[0]), int(par[1])
             terms = ["*".join(r[k * nf:(k + 1) * nf]) for k in range(ns)]
@@ -161,54 +168,80 @@ class Lowering:
                         lines.append(cur)
                         cur, nSums = [], 0
             lines.append(cur)
-            expr = "+".join(lines[0])
+            e = "+".join(lines[0])
             for ln in lines[1:]:
-                expr = f"({expr})+({'+'.join(ln)})"
-            return self.assign(i, expr)
+                e = f"({e})+({'+'.join(ln)})"
+            return e
         if typ == I.I_div:
-            return self.assign(i, f"{r[0]}/{r[1]}")
+            return f"{r[0]}/{r[1]}"
         if typ in (I.I_minus_dot, I.I_minus_dot_div, I.I_plus_minus_dot, I.I_plus_minus_dot_div):
             skip = {I.I_minus_dot: 0, I.I_minus_dot_div: 1, I.I_plus_minus_dot: 1,
                     I.I_plus_minus_dot_div: 2}[typ]
             d = r[skip:]
             dot = "+".join(f"{d[k]}*{d[k + 1]}" for k in range(0, len(d), 2))
             if typ == I.I_minus_dot:
-                return self.assign(i, f"-({dot})")
+                return f"-({dot})"
             if typ == I.I_minus_dot_div:
-                return self.assign(i, f"-({dot})/{r[0]}")
+                return f"-({dot})/{r[0]}"
             if typ == I.I_plus_minus_dot:
-                return self.assign(i, f"{r[0]}-({dot})")
-            return self.assign(i, f"({r[0]}-({dot}))/{r[1]}")
+                return f"{r[0]}-({dot})"
+            return f"({r[0]}-({dot}))/{r[1]}"
         if typ == I.I_plus_sqr:
-            return self.assign(i, "+".join(f"{x}*{x}" for x in r))
+            return "+".join(f"{x}*{x}" for x in r)
         if typ == I.I_plus_abs:
-            return self.assign(i, "+".join(f"fabs({x})" for x in r))
-        if typ in (I.I_min, I.I_min0, I.I_max, I.I_max0, I.I_max_abs, I.I_clp):
-            b = "  double a_;\n" if False else ""
-            if typ == I.I_clp:
-                body = "  { double a_=DBL_MAX;\n"
-                for k in range(0, len(r), 2):
-                    body += f"    if ({r[k + 1]}<0) {{ const double x_=-{r[k]}/{r[k + 1]}; if (a_>x_) a_=x_; }}\n"
-            elif typ == I.I_max_abs:
-                body = f"  {{ double a_=fabs({r[0]});\n"
-                for x in r[1:]:
-                    body += f"    if (a_<fabs({x})) a_=fabs({x});\n"
-            else:
-                cmp_ = ">" if typ in (I.I_min, I.I_min0) else "<"
-                if typ in (I.I_min, I.I_max):
-                    body = f"  {{ double a_={r[0]};\n"
-                    rest = r[1:]
-                else:
-                    body = "  { double a_=0;\n"
-                    rest = r
-                for x in rest:
-                    body += f"    if (a_{cmp_}{x}) a_={x};\n"
-            if self.local[i]:
-                return f"  double t{i};\n" + body + f"    t{i}=a_; }}\n"
-            return body + f"    MM({self.pslot[i]})=a_; }}\n"
+            return "+".join(f"fabs({x})" for x in r)
+        if typ in (I.I_min, I.I_max):
+            f = "tc_min" if typ == I.I_min else "tc_max"
+            e = r[0]
+            for x in r[1:]:
+                e = f"{f}({e},{x})"
+            return e
+        if typ in (I.I_min0, I.I_max0):
+            f = "tc_min" if typ == I.I_min0 else "tc_max"
+            e = "0.0"
+            for x in r:
+                e = f"{f}({e},{x})"
+            return e
+        if typ == I.I_max_abs:
+            e = f"fabs({r[0]})"
+            for x in r[1:]:
+                e = f"tc_max({e},fabs({x}))"
+            return e
+        if typ == I.I_clp:
+            e = "DBL_MAX"
+            for k in range(0, len(r), 2):
+                e = f"tc_clp({e},{r[k]},{r[k + 1]})"
+            return e
         if typ in _UNARY:
-            return self.assign(i, _UNARY[typ].format(r[0] if r else ""))
+            return _UNARY[typ].format(r[0] if r else "")
         raise NotImplementedError(f"HIP emitter: opcode {I.NAMES.get(typ, typ)} not supported")
+
+    # statements ------------------------------------------------------------------------------------
+    def group_body(self, g):
+        """HIP statements of dependency group g (1-based)"""
+        L = self.L
+        out = []
+        for i in L.T.groups[g - 1]:
+            i = int(i)
+            if L.inline[i]:
+                continue
+            fam = L.families.get(i)
+            if fam is not None:
+                e = self.expr(fam.template, fam)
+                dst = f"{fam.dst0}+c_" if fam.ddst == 1 else f"{fam.dst0}+{fam.ddst}*c_"
+                out.append(f"  for (int c_ = 0; c_ < {fam.n}; c_++) {{ MM({dst}) = {e}; }}\n")
+                continue
+            if L.in_family[i]:
+                continue
+            e = self.expr(L.tree(i))
+            if L.local[i]:
+                out.append(f"  const double t{i} = {e};\n")
+            else:
+                out.append(f"  MM({L.pslot[i]}) = {e};\n")
+        return "".join(out)
+
+    def ref(self, i):
+        return self.leaf_text(self.L.leaf(i))
 
 
 def _mask(groups):
@@ -218,18 +251,21 @@ def _mask(groups):
     return m
 
 
-def emit_class(spec, fp_contract="fast", block=64, stats=False):
+def emit_class(spec, fp_contract="fast", block=64, stats=False, roll=True, min_waves=0):
     """Return the HIP source text of the solver class."""
     T = spec.tape
-    L = Lowering(T)
+    L = Lowering(T, getattr(spec, "code", None), roll=roll)
+    P = Printer(L, roll=roll)
     cls = spec.classname
     nW = max(1, (T.nGroups + 63) // 64)
     w = []
     w.append(f"// GENERATED by tenscalc_amd.hip_emitter for class '{cls}' -- do not edit.\n"
              f"// tape: {T.n} instructions, {T.nGroups} dependency groups, {L.nPriv} private doubles,"
-             f" {L.nExt} input doubles per instance\n")
+             f" {L.nExt} input doubles per instance, {len(L.families)} rolled element families\n")
     w.append("#include <hip/hip_runtime.h>\n#include <math.h>\n#include <float.h>\n#include <stdint.h>\n\n")
     w.append(f'#define TC_CLASSNAME "{cls}"\n#define TC_BLOCK {int(block)}\n')
+    lb = f"__launch_bounds__(TC_BLOCK, {int(min_waves)})" if min_waves else "__launch_bounds__(TC_BLOCK)"
+    w.append(f"#define TC_LAUNCH_BOUNDS {lb}\n")
     if stats:
         w.append("#define TC_STATS 1\n")
     w.append("// solver configuration (reference: cmex2optimizeCS.m:303-331)\n")
@@ -243,24 +279,32 @@ def emit_class(spec, fp_contract="fast", block=64, stats=False):
     nOut = sum(int(np.prod(sz)) if len(sz) else 1 for _, sz in spec.outputs)
     w.append(f"#define TC_NM {max(1, L.nPriv)}\n#define TC_NEXT {L.nExt}\n#define TC_NOUT {nOut}\n"
              f"#define TC_NGROUPS {T.nGroups}\n#define TC_NSTW {nW}\n\n")
-    w.append("struct TcCtx {\n  double m[TC_NM];\n  const double *__restrict__ S;\n  long B, tid;\n"
+    w.append("// per-instance state: m = private scratch (values crossing group boundaries), S = this\n"
+             "// instance's column of the structure-of-arrays input block (element k at S[k*B])\n"
+             "typedef __attribute__((address_space(5))) double *tc_priv;\n"
+             "typedef const __attribute__((address_space(1))) double *tc_glob;\n"
+             "struct TcCtx {\n  tc_priv m;\n  tc_glob S;\n  long B;\n"
              "  unsigned long long st[TC_NSTW];\n#ifdef TC_STATS\n  int nMinF;\n#endif\n};\n"
-             "#define SX(k) (c.S[(long)(k) * c.B + c.tid])\n#define MM(k) (c.m[k])\n\n")
+             "#define SX(k) (S[(long)(k) * B])\n#define MM(k) (m[k])\n"
+             "#define TC_UNPACK tc_priv m = c.m; tc_glob S = c.S; const long B = c.B; (void)m; (void)S; (void)B;\n"
+             "static __device__ __forceinline__ double tc_min(double a, double x) { return (a > x) ? x : a; }\n"
+             "static __device__ __forceinline__ double tc_max(double a, double x) { return (a < x) ? x : a; }\n"
+             "// I_clp step: if (dx<0) { t=-x/dx; if (a>t) a=t; }  (instructionsTableUTHash.c:1315-1331)\n"
+             "static __device__ __forceinline__ double tc_clp(double a, double x, double dx) {\n"
+             "  if (dx < 0) { const double t = -x / dx; if (a > t) a = t; }\n  return a;\n}\n\n")
     # dependency groups ------------------------------------------------------------------
     for g, members in enumerate(T.groups, 1):
         w.append(f"// group {g}: {len(members)} instructions, {int(T.flops[g].sum())} flops\n")
-        w.append(f"static __device__ __noinline__ void tc_grp{g}(TcCtx &c) {{\n")
-        for i in members:
-            w.append(L.statement(int(i)))
+        w.append(f"static __device__ __noinline__ void tc_grp{g}(tc_priv m, tc_glob S, const long B) {{\n")
+        w.append(P.group_body(g))
         w.append("}\n")
     w.append("\n#define TC_NEED(g) do { if (!((c.st[((g)-1)>>6] >> (((g)-1)&63)) & 1ull)) { "
-             "c.st[((g)-1)>>6] |= 1ull << (((g)-1)&63); tc_grp##g(c); } } while (0)\n")
+             "c.st[((g)-1)>>6] |= 1ull << (((g)-1)&63); tc_grp##g(c.m, c.S, c.B); } } while (0)\n")
 
     def inval(children):
         s = ""
         for wd in range(nW):
-            m = _mask([g for g in children if (g - 1) // 64 == wd]) >> (64 * wd) if False else \
-                sum(1 << ((g - 1) % 64) for g in children if (g - 1) // 64 == wd)
+            m = sum(1 << ((g - 1) % 64) for g in children if (g - 1) // 64 == wd)
             if m:
                 s += f"  c.st[{wd}] &= ~0x{m:x}ull;\n"
         return s
@@ -270,7 +314,7 @@ def emit_class(spec, fp_contract="fast", block=64, stats=False):
     for e in T.sets:
         if e["external"]:
             continue
-        w.append(f"static __device__ __forceinline__ void {e['name']}(TcCtx &c, const double *input) {{\n")
+        w.append(f"static __device__ __forceinline__ void {e['name']}(TcCtx &c, const double *input) {{\n  TC_UNPACK\n")
         for k, i in enumerate(e["ins"]):
             if L.pslot[i] >= 0:
                 w.append(f"  MM({L.pslot[i]}) = input[{k}];\n")
@@ -278,22 +322,22 @@ def emit_class(spec, fp_contract="fast", block=64, stats=False):
         w.append("}\n")
     for e in T.gets:
         args = ", ".join(f"double *y{k + 1}" for k in range(len(e["outputs"])))
-        w.append(f"static __device__ __forceinline__ void {e['name']}(TcCtx &c, {args}) {{\n")
+        w.append(f"static __device__ __forceinline__ void {e['name']}(TcCtx &c, {args}) {{\n  TC_UNPACK\n")
         for g in e["parents"]:
             w.append(f"  TC_NEED({g});\n")
         for k, o in enumerate(e["outputs"]):
             for j, i in enumerate(o["ins"]):
-                w.append(f"  y{k + 1}[{j}] = {L.ref(i)};\n")
+                w.append(f"  y{k + 1}[{j}] = {P.ref(i)};\n")
         w.append("}\n")
     for e in T.copies:
-        w.append(f"static __device__ __forceinline__ void {e['name']}(TcCtx &c) {{\n")
+        w.append(f"static __device__ __forceinline__ void {e['name']}(TcCtx &c) {{\n  TC_UNPACK\n")
         for g in e["parents"]:
             w.append(f"  TC_NEED({g});\n")
-        for d, s in zip(e["dst"], e["src"]):
+        for d, s_ in zip(e["dst"], e["src"]):
             if L.external[d]:
                 raise NotImplementedError("copy into an external set")
             if L.pslot[d] >= 0:
-                w.append(f"  MM({L.pslot[d]}) = {L.ref(s)};\n")
+                w.append(f"  MM({L.pslot[d]}) = {P.ref(s_)};\n")
         w.append(inval(e["children"]))
         w.append("}\n")
     # entry points the loop may reference under #if but that this problem does not have
@@ -301,12 +345,12 @@ def emit_class(spec, fp_contract="fast", block=64, stats=False):
     w.append(f'#include "ipm_newton.hip.inc"\n\n')
     # kernels -------------------------------------------------------------------------------
     outs = T.entry(f"{cls}_getOutputs")[2]["outputs"]
-    w.append("extern \"C\" __global__ void __launch_bounds__(TC_BLOCK)\n"
+    w.append("extern \"C\" __global__ void TC_LAUNCH_BOUNDS\n"
              "tc_solve_kernel(const double *__restrict__ S, double *__restrict__ O, int *__restrict__ status,\n"
              "                int *__restrict__ iter, double mu0, int maxIter, double ae0, double ae1, long B) {\n"
              "  const long tid = (long)blockIdx.x * TC_BLOCK + threadIdx.x;\n"
              "  if (tid >= B) return;\n"
-             "  TcCtx c;\n  c.S = S;\n  c.B = B;\n  c.tid = tid;\n"
+             "  double mm_[TC_NM];\n  TcCtx c;\n  c.m = (tc_priv)mm_;\n  c.S = (tc_glob)(S + tid);\n  c.B = B;\n"
              "  for (int k = 0; k < TC_NSTW; k++) c.st[k] = 0;\n"
              "#ifdef TC_STATS\n  c.nMinF = 0;\n#endif\n"
              "  int st = 0, it = 0;\n"
@@ -328,7 +372,7 @@ def emit_class(spec, fp_contract="fast", block=64, stats=False):
              "                double ae0, double ae1, long B) {\n"
              "  const long tid = (long)blockIdx.x * TC_BLOCK + threadIdx.x;\n"
              "  if (tid >= B) return;\n"
-             "  TcCtx c;\n  c.S = S;\n  c.B = B;\n  c.tid = tid;\n"
+             "  double mm_[TC_NM];\n  TcCtx c;\n  c.m = (tc_priv)mm_;\n  c.S = (tc_glob)(S + tid);\n  c.B = B;\n"
              "  for (int k = 0; k < TC_NSTW; k++) c.st[k] = 0;\n"
              "#if setAddEye2Hessian != 0\n  setAddEye2HessianU__(c, &ae0);\n  setAddEye2HessianEq__(c, &ae1);\n#endif\n"
              "  initPrimal__(c);\n"
@@ -420,7 +464,7 @@ def class_header(spec):
 
 
 def build_class(spec, fp_contract="fast", arch="gfx950", opt="-O3", block=64, force=False,
-                outdir=None, stats=False, tag=None, extra_flags=()):
+                outdir=None, stats=False, tag=None, extra_flags=(), roll=True, min_waves=0):
     """Emit <cls>.hip (+ <cls>.h, <cls>.tape) and compile lib<cls>.so with hipcc for gfx950.
     Mirrors the createGateway/compile step of cmex2optimizeCS.m:403-417."""
     from .tapeio import save_tape
@@ -428,7 +472,8 @@ def build_class(spec, fp_contract="fast", arch="gfx950", opt="-O3", block=64, fo
     outdir = outdir or os.path.join(spec.folder, f"@{cls}")
     os.makedirs(outdir, exist_ok=True)
     suffix = f"_{tag}" if tag else ""
-    src, L = emit_class(spec, fp_contract=fp_contract, block=block, stats=stats)
+    src, L = emit_class(spec, fp_contract=fp_contract, block=block, stats=stats, roll=roll,
+                        min_waves=min_waves)
     hip = os.path.join(outdir, f"{cls}{suffix}.hip")
     so = os.path.join(outdir, f"lib{cls}{suffix}.so")
     flags = [opt, f"--offload-arch={arch}", "-fPIC", "-shared", "-std=c++17",

@@ -1,0 +1,322 @@
+"""Tape analysis shared by the HIP lowerings: storage classes, expression inlining and affine
+instruction families.
+
+The reference's C emitter rolls >=50 consecutive same-shape instructions with constant operand
+strides into a ``for`` loop (/root/reference/lib/csparse/instructionsTableUTHash.c:881-944,
+``minInstructions4loop`` parameters4all.m:438-447).  We recover the same regularity from better
+information: every vectorized tensor operation remembers the scalar instructions it produced
+(``CSparse.cache``), so each tensor node is a candidate *family* -- same opcode/shape, operands in
+arithmetic progression of storage index.  Two kinds are recognised:
+
+* V1  element families: n instructions ``out[c] = f(leaf_0[b0+d0*c], leaf_1[b1+d1*c], ...)``;
+* V2  term families inside one long ``I_sumprod``/``I_plus_sqr``: ``sum_k prod_p leaf_p[b+d*k]``.
+
+Values used once inside their own dependency group are inlined into the consumer as nested
+(parenthesised) expressions, which keeps the reference's evaluation order exactly.
+"""
+from __future__ import annotations
+
+import numpy as np
+
+from . import instructions as I
+
+MAX_TERMS_PERLINE = 100   # instructionsTableUTHash.c:173
+V1_MIN = 6                # smallest element family rolled into a loop
+V2_MIN = 12               # smallest term family rolled into a loop
+
+
+class Leaf:
+    __slots__ = ("ins", "kind", "idx", "val")
+
+    def __init__(self, ins, kind, idx, val=None):
+        self.ins, self.kind, self.idx, self.val = ins, kind, idx, val
+
+
+class Node:
+    __slots__ = ("ins", "typ", "par", "kids")
+
+    def __init__(self, ins, typ, par, kids):
+        self.ins, self.typ, self.par, self.kids = ins, typ, par, kids
+
+
+class Family:
+    """V1 element family: members (instruction ids) share one template tree; leaf j of member c is
+    at index base[j] + delta[j]*c; destination private slot dst0 + ddst*c."""
+
+    def __init__(self, members, template, base, delta, dst0, ddst):
+        self.members, self.template = members, template
+        self.base, self.delta, self.dst0, self.ddst = base, delta, dst0, ddst
+        self.n = len(members)
+
+
+class Lowering:
+    def __init__(self, tape, code=None, roll=True):
+        T = self.T = tape
+        n = T.n
+        opl, ost = T.ops.tolist(), T.opStart.tolist()
+        self._opl, self._ost = opl, ost
+        grp = T.group
+        # ---- external inputs (parameters / initial values): SoA block S --------------------
+        self.external = np.zeros(n + 1, dtype=bool)
+        self.ext_index = np.full(n + 1, -1, dtype=np.int64)
+        self.inputs = []
+        off = 0
+        for e in T.sets:
+            if e["external"]:
+                self.external[e["ins"]] = True
+                self.ext_index[e["ins"]] = off + np.arange(len(e["ins"]))
+                self.inputs.append(dict(name=e["varname"], entry=e["name"], size=e["size"],
+                                        numel=len(e["ins"]), off=off))
+                off += len(e["ins"])
+        self.nExt = off
+        out_needed = np.zeros(n + 1, dtype=bool)   # read by a get / copy source
+        for e in T.gets:
+            for o in e["outputs"]:
+                out_needed[o["ins"]] = True
+        for e in T.copies:
+            out_needed[e["src"]] = True
+        self.out_needed = out_needed
+        # ---- readers -------------------------------------------------------------------------
+        nread = np.zeros(n + 1, dtype=np.int64)       # in-tape readers (used instructions only)
+        read_other = np.zeros(n + 1, dtype=bool)      # read from another group
+        for i in range(1, n + 1):
+            if not T.used[i] or grp[i] == 0:
+                continue
+            seen = set()
+            for j in opl[ost[i - 1]:ost[i]]:
+                if j in seen:
+                    nread[j] += 1       # same consumer twice still counts (x*x)
+                    continue
+                seen.add(j)
+                nread[j] += 1
+                if grp[j] != grp[i]:
+                    read_other[j] = True
+        self.nread = nread
+        computed = np.zeros(n + 1, dtype=bool)
+        computed[1:] = (grp[1:] > 0)
+        local = computed & ~read_other & ~out_needed
+        # inline: local value with exactly one reader (one operand slot)
+        inline = local & (nread == 1)
+        self.computed = computed
+        self.inline = inline
+        self.local = local & ~inline                     # SSA temporaries
+        self.promote = np.zeros(n + 1, dtype=bool)       # temporaries forced into memory
+        # ---- candidate families from tensor nodes ---------------------------------------------------
+        self.families = {}          # first member id -> Family
+        self.in_family = np.zeros(n + 1, dtype=bool)
+        cands = []
+        if roll and code is not None:
+            seen = set()
+            for _, (subs, ins) in code.cache.items():
+                if ins.size < V1_MIN:
+                    continue
+                key = (int(ins[0]), int(ins[-1]), ins.size)
+                if key in seen:
+                    continue
+                seen.add(key)
+                cands.append(ins)
+        fam_members = []
+        for ins in cands:
+            m = self._family_precheck(ins)
+            if m is not None:
+                fam_members.append(m)
+        # members (and their strided computed leaves) must live in indexable memory
+        for m in fam_members:
+            for i in m:
+                if self.local[i]:
+                    self.promote[i] = True
+        self.local &= ~self.promote
+        # ---- private slots: families first (contiguous), then everything else ---------------------------
+        read_any = np.zeros(n + 1, dtype=bool)
+        for i in range(1, n + 1):
+            if T.used[i]:
+                for j in opl[ost[i - 1]:ost[i]]:
+                    read_any[j] = True
+        read_any |= out_needed
+        pslot = np.full(n + 1, -1, dtype=np.int64)
+        k = 0
+        for m in fam_members:
+            for i in m:
+                if pslot[i] < 0 and not self.inline[i]:
+                    pslot[i] = k
+                    k += 1
+        for i in range(1, n + 1):
+            if pslot[i] >= 0:
+                continue
+            if T.isset[i - 1]:
+                if not self.external[i] and read_any[i]:
+                    pslot[i] = k
+                    k += 1
+            elif computed[i] and not self.local[i] and not self.inline[i]:
+                pslot[i] = k
+                k += 1
+        self.pslot = pslot
+        self.nPriv = k
+        # ---- verify families against the final storage -----------------------------------------------------
+        self._tree_cache = {}
+        for m in fam_members:
+            if self.in_family[m].any():
+                continue
+            f = self._family_verify(m)
+            if f is not None:
+                self.families[min(m)] = f
+                self.in_family[m] = True
+
+    # -------------------------------------------------------------------------------------------
+    def operands(self, i):
+        return self._opl[self._ost[i - 1]:self._ost[i]]
+
+    def leaf(self, j):
+        T = self.T
+        j = int(j)
+        if T.isload[j - 1]:
+            return Leaf(j, "lit", -1, float(T.pars[T.parStart[j - 1]]))
+        if self.external[j]:
+            return Leaf(j, "ext", int(self.ext_index[j]))
+        if self.local[j]:
+            return Leaf(j, "tmp", j)
+        if self.pslot[j] < 0:
+            raise AssertionError(f"instruction {j} has no storage")
+        return Leaf(j, "priv", int(self.pslot[j]))
+
+    def tree(self, i):
+        """expression tree of instruction i with single-use local operands inlined"""
+        t = self._tree_cache.get(i)
+        if t is None:
+            typ, par, ops = self.T.instr(i)
+            kids = [self.tree(int(o)) if self.inline[o] else self.leaf(o) for o in ops]
+            t = Node(i, typ, tuple(float(p) for p in par), kids)
+            self._tree_cache[i] = t
+        return t
+
+    def shape_sig(self, i, depth=0):
+        """structure signature that ignores storage (used before slots exist)"""
+        typ, par, ops = self.T.instr(i)
+        kids = []
+        for o in ops:
+            o = int(o)
+            if self.inline[o]:
+                kids.append(self.shape_sig(o, depth + 1))
+            elif self.T.isload[o - 1]:
+                kids.append(("lit", float(self.T.pars[self.T.parStart[o - 1]])))
+            else:
+                kids.append("v")
+        return (typ, tuple(float(p) for p in par), tuple(kids))
+
+    def _family_precheck(self, ins):
+        T = self.T
+        ins = [int(i) for i in ins]
+        if len(set(ins)) != len(ins):
+            return None
+        g = T.group[ins[0]]
+        if g == 0:
+            return None
+        for i in ins:
+            if T.group[i] != g or self.inline[i] or not self.computed[i]:
+                return None
+        s0 = self.shape_sig(ins[0])
+        for i in ins[1:]:
+            if self.shape_sig(i) != s0:
+                return None
+        # every leaf operand must exist before the first member is evaluated
+        first = min(ins)
+        mem = set(ins)
+        for i in ins:
+            for j in self._leaf_ids(i):
+                if j in mem:
+                    return None
+                if j > first and T.group[j] == g:
+                    return None
+        return ins
+
+    def _leaf_ids(self, i):
+        out = []
+        for o in self.operands(i):
+            if self.inline[o]:
+                out += self._leaf_ids(int(o))
+            else:
+                out.append(int(o))
+        return out
+
+    @staticmethod
+    def flat_leaves(t, acc=None):
+        if acc is None:
+            acc = []
+        for k in t.kids:
+            if isinstance(k, Leaf):
+                acc.append(k)
+            else:
+                Lowering.flat_leaves(k, acc)
+        return acc
+
+    def _family_verify(self, members):
+        trees = [self.tree(i) for i in members]
+        L0 = self.flat_leaves(trees[0])
+        n = len(members)
+        base = [lf.idx for lf in L0]
+        delta = [0] * len(L0)
+        if n > 1:
+            L1 = self.flat_leaves(trees[1])
+            if len(L1) != len(L0):
+                return None
+            delta = [b.idx - a.idx for a, b in zip(L0, L1)]
+        for c, t in enumerate(trees):
+            Lc = self.flat_leaves(t)
+            if len(Lc) != len(L0):
+                return None
+            for j, lf in enumerate(Lc):
+                if lf.kind != L0[j].kind:
+                    return None
+                if lf.kind == "lit":
+                    if lf.val != L0[j].val:
+                        return None
+                elif lf.kind == "tmp":
+                    if lf.idx != L0[j].idx:
+                        return None
+                elif lf.idx != base[j] + delta[j] * c:
+                    return None
+        d = [int(self.pslot[i]) for i in members]
+        if min(d) < 0:
+            return None
+        dd = d[1] - d[0] if n > 1 else 0
+        if any(d[c] != d[0] + dd * c for c in range(n)):
+            return None
+        return Family(list(members), trees[0], base, delta, d[0], dd)
+
+    # ---- V2: affine term families inside a long sum ---------------------------------------------------
+    @staticmethod
+    def term_family(node, leaf_base, leaf_delta, leaf_pos):
+        """For a sumprod/plus_sqr ``node`` whose kids are all leaves: returns per-factor
+        (kind, base, dk, dc) lists if terms form an arithmetic progression, else None.
+        leaf_base/leaf_delta: per-leaf V1 base/delta (delta==0 outside families);
+        leaf_pos: index of node's first leaf in the flattened leaf list."""
+        if node.typ == I.I_sumprod:
+            nf, ns = int(node.par[0]), int(node.par[1])
+        elif node.typ == I.I_plus_sqr:
+            nf, ns = 1, len(node.kids)
+        else:
+            return None
+        if ns < V2_MIN or any(not isinstance(k, Leaf) for k in node.kids):
+            return None
+        out = []
+        for p in range(nf):
+            l0 = node.kids[p]
+            b0 = leaf_base[leaf_pos + p]
+            dc = leaf_delta[leaf_pos + p]
+            dk = (leaf_base[leaf_pos + nf + p] - b0) if ns > 1 else 0
+            for k in range(ns):
+                lf = node.kids[k * nf + p]
+                if lf.kind != l0.kind:
+                    return None
+                if lf.kind == "lit":
+                    if lf.val != l0.val:
+                        return None
+                    continue
+                if lf.kind == "tmp":
+                    if lf.idx != l0.idx:
+                        return None
+                    continue
+                if leaf_base[leaf_pos + k * nf + p] != b0 + dk * k or leaf_delta[leaf_pos + k * nf + p] != dc:
+                    return None
+            out.append((l0.kind, b0, dk, dc, l0))
+        return nf, ns, out
