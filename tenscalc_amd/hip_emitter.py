@@ -84,12 +84,67 @@ class Printer:
             ix += f"+{dk}*k_" if dk != 1 else "+k_"
         return f"SX({ix})" if lf.kind == "ext" else f"MM({ix})"
 
+    def vec_ref(self, vec, k):
+        """element block k of a distributed vector as seen by one lane (register array)"""
+        L = self.L
+        if vec[0] == "X":
+            d = [x for x in L.inputs if x["dist"] and x["arr"] == vec[1]][0]
+            return f"c.dX{vec[1]}[{vec[2] * d['K'] + k}]"
+        return f"c.dF{vec[1]}[{k}]"
+
+    def reduction(self, t):
+        """sum over aligned distributed operands: per-lane partial sum + butterfly all-reduce"""
+        L = self.L
+        nf, ns, facs = L.dreduce[t.ins]
+        P_ = L.P
+        K = -(-ns // P_)
+        terms = []
+        for k in range(K):
+            fs = []
+            for p, (kind, v) in enumerate(facs):
+                if kind == "d":
+                    fs.append(self.vec_ref(v, k))
+                else:
+                    fs.append(self.leaf_text(t.kids[p]))
+            tk = f"{fs[0]}*{fs[0]}" if t.typ == I.I_plus_sqr else "*".join(fs)
+            if (k + 1) * P_ > ns:
+                tk = f"(({k * P_}+c.lane<{ns})?({tk}):0.0)"
+            terms.append(tk)
+        e = terms[0]
+        for tk in terms[1:]:
+            e = f"({e})+{tk}"
+        return f"tc_allreduce({e})"
+
+    def dfamily_body(self, f):
+        L = self.L
+        K = -(-f.n // L.P)
+        out = []
+        for k in range(K):
+            pos = [0]
+            e = self._dexpr(f.template, f, k, pos)
+            out.append(f"  c.dF{f.fid}[{k}] = {e};\n")
+        return "".join(out)
+
+    def _dexpr(self, t, f, k, pos):
+        r = []
+        for kid in t.kids:
+            if isinstance(kid, Leaf):
+                kind, v = f.leaves[pos[0]]
+                pos[0] += 1
+                r.append(self.vec_ref(v, k) if kind == "d" else self.leaf_text(v))
+            else:
+                r.append("(" + self._dexpr(kid, f, k, pos) + ")")
+        return self.op_text(t.typ, t.par, r)
+
     def expr(self, t, fam=None, pos=None):
         """C expression of tree t.  fam: Family (leaf index = base+delta*c_) or None.
         pos: running index into the flattened leaf list (list of one int)."""
         if pos is None:
             pos = [0]
         L = self.L
+        if t.ins in L.dreduce:
+            pos[0] += len(t.kids)
+            return self.reduction(t)
         base = fam.base if fam else None
         delta = fam.delta if fam else None
         # V2: long sums rolled over the term index k_
@@ -225,6 +280,10 @@ class Printer:
             i = int(i)
             if L.inline[i]:
                 continue
+            dfam = L.dfamilies.get(i)
+            if dfam is not None:
+                out.append(self.dfamily_body(dfam))
+                continue
             fam = L.families.get(i)
             if fam is not None:
                 e = self.expr(fam.template, fam)
@@ -243,6 +302,14 @@ class Printer:
     def ref(self, i):
         return self.leaf_text(self.L.leaf(i))
 
+    def group_uses_distributed(self, g):
+        L = self.L
+        for i in L.T.groups[g - 1]:
+            i = int(i)
+            if i in L.dval or i in L.dreduce:
+                return True
+        return False
+
 
 def _mask(groups):
     m = 0
@@ -251,10 +318,18 @@ def _mask(groups):
     return m
 
 
-def emit_class(spec, fp_contract="fast", block=64, stats=False, roll=True, min_waves=0):
-    """Return the HIP source text of the solver class."""
+def emit_class(spec, fp_contract="fast", block=64, stats=False, roll=True, min_waves=0, lanes=1):
+    """Return the HIP source text of the solver class.
+
+    lanes=1: one thread per problem instance (generic lowering, bit-exact with fp_contract='off').
+    lanes=P>1: P lanes cooperate on one instance -- large inputs and the element families built on
+    them are distributed over the lanes (register-resident for the whole solve, read from HBM
+    once), long sums become per-lane partial sums + a DPP butterfly all-reduce, everything else is
+    computed redundantly by the P lanes on per-instance state held in LDS."""
     T = spec.tape
-    L = Lowering(T, getattr(spec, "code", None), roll=roll)
+    L = Lowering(T, getattr(spec, "code", None), roll=roll, lanes=lanes)
+    if block % lanes:
+        raise ValueError("block must be a multiple of lanes")
     P = Printer(L, roll=roll)
     cls = spec.classname
     nW = max(1, (T.nGroups + 63) // 64)
@@ -263,7 +338,8 @@ def emit_class(spec, fp_contract="fast", block=64, stats=False, roll=True, min_w
              f"// tape: {T.n} instructions, {T.nGroups} dependency groups, {L.nPriv} private doubles,"
              f" {L.nExt} input doubles per instance, {len(L.families)} rolled element families\n")
     w.append("#include <hip/hip_runtime.h>\n#include <math.h>\n#include <float.h>\n#include <stdint.h>\n\n")
-    w.append(f'#define TC_CLASSNAME "{cls}"\n#define TC_BLOCK {int(block)}\n')
+    w.append(f'#define TC_CLASSNAME "{cls}"\n#define TC_BLOCK {int(block)}\n#define TC_P {int(lanes)}\n'
+             f"#define TC_G (TC_BLOCK / TC_P)\n#define TC_NDIST {L.nDist}\n")
     lb = f"__launch_bounds__(TC_BLOCK, {int(min_waves)})" if min_waves else "__launch_bounds__(TC_BLOCK)"
     w.append(f"#define TC_LAUNCH_BOUNDS {lb}\n")
     if stats:
@@ -279,27 +355,46 @@ def emit_class(spec, fp_contract="fast", block=64, stats=False, roll=True, min_w
     nOut = sum(int(np.prod(sz)) if len(sz) else 1 for _, sz in spec.outputs)
     w.append(f"#define TC_NM {max(1, L.nPriv)}\n#define TC_NEXT {L.nExt}\n#define TC_NOUT {nOut}\n"
              f"#define TC_NGROUPS {T.nGroups}\n#define TC_NSTW {nW}\n\n")
-    w.append("// per-instance state: m = private scratch (values crossing group boundaries), S = this\n"
-             "// instance's column of the structure-of-arrays input block (element k at S[k*B])\n"
+    dmembers = ""
+    for d in L.inputs:
+        if d["dist"]:
+            dmembers += f"  double dX{d['arr']}[{d['rest'] * d['K']}];\n"
+    for f in L.dfamilies.values():
+        dmembers += f"  double dF{f.fid}[{-(-f.n // L.P)}];\n"
+    mem_t = "tc_priv" if lanes == 1 else "tc_lds"
+    mm = "(m[k])" if lanes == 1 else "(m[(k) * TC_G])"
+    w.append("// per-instance state: m = scratch for values crossing group boundaries (private memory when\n"
+             "// one thread owns the instance, LDS [slot][instance] when TC_P lanes share it), S = this\n"
+             "// instance's column of the structure-of-arrays input block (element k at S[k*B]), dX*/dF* =\n"
+             "// this lane's share of the distributed vectors (registers)\n"
              "typedef __attribute__((address_space(5))) double *tc_priv;\n"
+             "typedef __attribute__((address_space(3))) double *tc_lds;\n"
              "typedef const __attribute__((address_space(1))) double *tc_glob;\n"
-             "struct TcCtx {\n  tc_priv m;\n  tc_glob S;\n  long B;\n"
-             "  unsigned long long st[TC_NSTW];\n#ifdef TC_STATS\n  int nMinF;\n#endif\n};\n"
-             "#define SX(k) (S[(long)(k) * B])\n#define MM(k) (m[k])\n"
-             "#define TC_UNPACK tc_priv m = c.m; tc_glob S = c.S; const long B = c.B; (void)m; (void)S; (void)B;\n"
+             f"typedef {mem_t} tc_mem;\n"
+             "struct TcCtx {\n  tc_mem m;\n  tc_glob S;\n  long B;\n  int lane;\n"
+             "  unsigned long long st[TC_NSTW];\n" + dmembers +
+             "#ifdef TC_STATS\n  int nMinF;\n#endif\n};\n"
+             f"#define SX(k) (S[(long)(k) * B])\n#define MM(k) {mm}\n"
+             "#define TC_UNPACK tc_mem m = c.m; tc_glob S = c.S; const long B = c.B; (void)m; (void)S; (void)B;\n"
              "static __device__ __forceinline__ double tc_min(double a, double x) { return (a > x) ? x : a; }\n"
              "static __device__ __forceinline__ double tc_max(double a, double x) { return (a < x) ? x : a; }\n"
              "// I_clp step: if (dx<0) { t=-x/dx; if (a>t) a=t; }  (instructionsTableUTHash.c:1315-1331)\n"
              "static __device__ __forceinline__ double tc_clp(double a, double x, double dx) {\n"
-             "  if (dx < 0) { const double t = -x / dx; if (a > t) a = t; }\n  return a;\n}\n\n")
+             "  if (dx < 0) { const double t = -x / dx; if (a > t) a = t; }\n  return a;\n}\n"
+             '#include "tc_wave.hip.inc"\n\n')
     # dependency groups ------------------------------------------------------------------
     for g, members in enumerate(T.groups, 1):
         w.append(f"// group {g}: {len(members)} instructions, {int(T.flops[g].sum())} flops\n")
-        w.append(f"static __device__ __noinline__ void tc_grp{g}(tc_priv m, tc_glob S, const long B) {{\n")
-        w.append(P.group_body(g))
-        w.append("}\n")
+        if P.group_uses_distributed(g):
+            w.append(f"static __device__ __forceinline__ void tc_grp{g}(TcCtx &c) {{\n  TC_UNPACK\n")
+            w.append(P.group_body(g))
+            w.append(f"}}\n#define TC_CALL_GRP{g} tc_grp{g}(c)\n")
+        else:
+            w.append(f"static __device__ __noinline__ void tc_grp{g}(tc_mem m, tc_glob S, const long B) {{\n")
+            w.append(P.group_body(g))
+            w.append(f"}}\n#define TC_CALL_GRP{g} tc_grp{g}(c.m, c.S, c.B)\n")
     w.append("\n#define TC_NEED(g) do { if (!((c.st[((g)-1)>>6] >> (((g)-1)&63)) & 1ull)) { "
-             "c.st[((g)-1)>>6] |= 1ull << (((g)-1)&63); tc_grp##g(c.m, c.S, c.B); } } while (0)\n")
+             "c.st[((g)-1)>>6] |= 1ull << (((g)-1)&63); TC_CALL_GRP##g; } } while (0)\n")
 
     def inval(children):
         s = ""
@@ -345,19 +440,32 @@ def emit_class(spec, fp_contract="fast", block=64, stats=False, roll=True, min_w
     w.append(f'#include "ipm_newton.hip.inc"\n\n')
     # kernels -------------------------------------------------------------------------------
     outs = T.entry(f"{cls}_getOutputs")[2]["outputs"]
+    # common kernel prologue: thread -> (instance, lane), per-instance state, distributed inputs
+    prologue = ("  const long t_ = (long)blockIdx.x * TC_BLOCK + threadIdx.x;\n"
+                "  const long tid = t_ / TC_P;\n"
+                "  if (tid >= B) return;\n"
+                "  TcCtx c;\n"
+                "#if TC_P == 1\n  double mm_[TC_NM];\n  c.m = (tc_priv)mm_;\n"
+                "#else\n  __shared__ double tc_lds_m[TC_NM * TC_G];\n  c.m = (tc_lds)&tc_lds_m[threadIdx.x / TC_P];\n#endif\n"
+                "  c.lane = (int)(t_ % TC_P);\n  c.S = (tc_glob)(S + tid);\n  c.B = B;\n"
+                "  for (int k = 0; k < TC_NSTW; k++) c.st[k] = 0;\n"
+                "#ifdef TC_STATS\n  c.nMinF = 0;\n#endif\n")
+    for d in L.inputs:
+        if d["dist"]:
+            cnt = d["rest"] * d["K"]
+            prologue += (f"  _Pragma(\"unroll\") for (int j = 0; j < {cnt}; j++) "
+                         f"c.dX{d['arr']}[j] = Sd[((long)({d['off']} + j) * B + tid) * TC_P + c.lane];\n")
+    outs = T.entry(f"{cls}_getOutputs")[2]["outputs"]
     w.append("extern \"C\" __global__ void TC_LAUNCH_BOUNDS\n"
-             "tc_solve_kernel(const double *__restrict__ S, double *__restrict__ O, int *__restrict__ status,\n"
-             "                int *__restrict__ iter, double mu0, int maxIter, double ae0, double ae1, long B) {\n"
-             "  const long tid = (long)blockIdx.x * TC_BLOCK + threadIdx.x;\n"
-             "  if (tid >= B) return;\n"
-             "  double mm_[TC_NM];\n  TcCtx c;\n  c.m = (tc_priv)mm_;\n  c.S = (tc_glob)(S + tid);\n  c.B = B;\n"
-             "  for (int k = 0; k < TC_NSTW; k++) c.st[k] = 0;\n"
-             "#ifdef TC_STATS\n  c.nMinF = 0;\n#endif\n"
+             "tc_solve_kernel(const double *__restrict__ S, const double *__restrict__ Sd, double *__restrict__ O,\n"
+             "                int *__restrict__ status, int *__restrict__ iter, double mu0, int maxIter, double ae0,\n"
+             "                double ae1, long B) {\n" + prologue +
              "  int st = 0, it = 0;\n"
              "  ipmPD_CSsolver(c, mu0, maxIter, ae0, ae1, &st, &it);\n")
     for k, o in enumerate(outs):
         w.append(f"  double y{k + 1}[{max(1, len(o['ins']))}];\n")
     w.append(f"  {cls}_getOutputs(c, " + ", ".join(f"y{k + 1}" for k in range(len(outs))) + ");\n")
+    w.append("  if (c.lane != 0) return;\n")
     off = 0
     out_meta = []
     for k, o in enumerate(outs):
@@ -368,12 +476,8 @@ def emit_class(spec, fp_contract="fast", block=64, stats=False, roll=True, min_w
     w.append("  status[tid] = st;\n  iter[tid] = it;\n}\n\n")
     # probe kernel: init sequence then one get
     w.append("extern \"C\" __global__ void __launch_bounds__(TC_BLOCK)\n"
-             "tc_probe_kernel(const double *__restrict__ S, double *__restrict__ out, int which, double mu0,\n"
-             "                double ae0, double ae1, long B) {\n"
-             "  const long tid = (long)blockIdx.x * TC_BLOCK + threadIdx.x;\n"
-             "  if (tid >= B) return;\n"
-             "  double mm_[TC_NM];\n  TcCtx c;\n  c.m = (tc_priv)mm_;\n  c.S = (tc_glob)(S + tid);\n  c.B = B;\n"
-             "  for (int k = 0; k < TC_NSTW; k++) c.st[k] = 0;\n"
+             "tc_probe_kernel(const double *__restrict__ S, const double *__restrict__ Sd, double *__restrict__ out,\n"
+             "                int which, double mu0, double ae0, double ae1, long B) {\n" + prologue +
              "#if setAddEye2Hessian != 0\n  setAddEye2HessianU__(c, &ae0);\n  setAddEye2HessianEq__(c, &ae1);\n#endif\n"
              "  initPrimal__(c);\n"
              "#if scaleCost != 0\n  scaleCost__(c);\n#endif\n"
@@ -391,7 +495,7 @@ def emit_class(spec, fp_contract="fast", block=64, stats=False, roll=True, min_w
         po = 0
         for q, o in enumerate(e["outputs"]):
             n_ = len(o["ins"])
-            w.append(f"      for (int j = 0; j < {n_}; j++) out[tid * {tot} + {po} + j] = y{q + 1}[j];\n")
+            w.append(f"      if (c.lane == 0) for (int j = 0; j < {n_}; j++) out[tid * {tot} + {po} + j] = y{q + 1}[j];\n")
             po += n_
         w.append("    } break;\n")
     w.append("    default: break;\n  }\n}\n\n")
@@ -411,6 +515,10 @@ def emit_class(spec, fp_contract="fast", block=64, stats=False, roll=True, min_w
     w.append(carr("int", "TC_IN_ISVAR", [int(i["name"] in isvar) for i in ins]))
     w.append(carr("int64_t", "TC_IN_NUMEL", [i["numel"] for i in ins]))
     w.append(carr("int64_t", "TC_IN_OFF", [i["off"] for i in ins]))
+    w.append(carr("int", "TC_IN_DIST", [int(i["dist"]) for i in ins]))
+    w.append(carr("int64_t", "TC_IN_N1", [i.get("n1", 0) for i in ins]))
+    w.append(carr("int64_t", "TC_IN_K", [i.get("K", 0) for i in ins]))
+    w.append(carr("int64_t", "TC_IN_REST", [i.get("rest", 0) for i in ins]))
     w.append(carr("int", "TC_IN_NDIM", [len(i["size"]) for i in ins]))
     w.append("static const int64_t TC_IN_DIMS[][8] = {" + ", ".join(dims8(i["size"]) for i in ins) + "};\n")
     w.append(f"static const int TC_NOUTS = {len(out_meta)};\n")
@@ -427,7 +535,9 @@ def emit_class(spec, fp_contract="fast", block=64, stats=False, roll=True, min_w
     w.append(carr("char *const", "TC_PROBE_NAME", [p[0] for p in probes], lambda s: f'"{s}"'))
     w.append(carr("int64_t", "TC_PROBE_NUMEL", [p[1] for p in probes]))
     stat = {"total_instructions": int(T.n), "used_instructions": int(T.used.sum()),
-            "groups": int(T.nGroups), "private_doubles": int(L.nPriv), "input_doubles": int(L.nExt),
+            "groups": int(T.nGroups), "private_doubles": int(L.nPriv), "input_doubles": int(sum(i["numel"] for i in ins)),
+            "lanes_per_instance": int(lanes), "distributed_families": len(L.dfamilies),
+            "distributed_reductions": len(L.dreduce), "rolled_families": len(L.families),
             "output_doubles": int(nOut), "flops_all_groups": int(T.flops.sum())}
     for g in range(1, T.nGroups + 1):
         stat[f"flops_group{g}"] = int(T.flops[g].sum())
@@ -464,7 +574,7 @@ def class_header(spec):
 
 
 def build_class(spec, fp_contract="fast", arch="gfx950", opt="-O3", block=64, force=False,
-                outdir=None, stats=False, tag=None, extra_flags=(), roll=True, min_waves=0):
+                outdir=None, stats=False, tag=None, extra_flags=(), roll=True, min_waves=0, lanes=1):
     """Emit <cls>.hip (+ <cls>.h, <cls>.tape) and compile lib<cls>.so with hipcc for gfx950.
     Mirrors the createGateway/compile step of cmex2optimizeCS.m:403-417."""
     from .tapeio import save_tape
@@ -473,12 +583,13 @@ def build_class(spec, fp_contract="fast", arch="gfx950", opt="-O3", block=64, fo
     os.makedirs(outdir, exist_ok=True)
     suffix = f"_{tag}" if tag else ""
     src, L = emit_class(spec, fp_contract=fp_contract, block=block, stats=stats, roll=roll,
-                        min_waves=min_waves)
+                        min_waves=min_waves, lanes=lanes)
     hip = os.path.join(outdir, f"{cls}{suffix}.hip")
     so = os.path.join(outdir, f"lib{cls}{suffix}.so")
     flags = [opt, f"--offload-arch={arch}", "-fPIC", "-shared", "-std=c++17",
              f"-ffp-contract={fp_contract}", "-I", CSRC, "-I", INCLUDE, "-Wno-unused-value"] + list(extra_flags)
     deps = [os.path.join(CSRC, "ipm_newton.hip.inc"), os.path.join(CSRC, "tc_runtime.hip.inc"),
+            os.path.join(CSRC, "tc_wave.hip.inc"),
             os.path.join(INCLUDE, "tenscalc_hip.h")]
     h = hashlib.sha256((src + " ".join(flags)).encode())
     for d in deps:

@@ -49,9 +49,21 @@ class Family:
         self.n = len(members)
 
 
+class DFamily:
+    """Element family whose members are DISTRIBUTED over the P lanes that share one problem
+    instance: member c is owned by lane c % P and lives in element c // P of a per-lane register
+    array.  leaves: per flattened template leaf, either ("d", vec) for an aligned distributed
+    operand (element c of vector `vec`) or ("r", Leaf) for a replicated operand."""
+
+    def __init__(self, fid, members, template, leaves):
+        self.fid, self.members, self.template, self.leaves = fid, members, template, leaves
+        self.n = len(members)
+
+
 class Lowering:
-    def __init__(self, tape, code=None, roll=True):
+    def __init__(self, tape, code=None, roll=True, lanes=1):
         T = self.T = tape
+        self.P = int(lanes)
         n = T.n
         opl, ost = T.ops.tolist(), T.opStart.tolist()
         self._opl, self._ost = opl, ost
@@ -61,14 +73,36 @@ class Lowering:
         self.ext_index = np.full(n + 1, -1, dtype=np.int64)
         self.inputs = []
         off = 0
+        doff = 0
+        self.dval = {}              # instruction id -> (vector key, element index)  [distributed values]
+        self.dvec_len = {}          # vector key -> number of elements
+        P = self.P
         for e in T.sets:
             if e["external"]:
-                self.external[e["ins"]] = True
-                self.ext_index[e["ins"]] = off + np.arange(len(e["ins"]))
-                self.inputs.append(dict(name=e["varname"], entry=e["name"], size=e["size"],
-                                        numel=len(e["ins"]), off=off))
-                off += len(e["ins"])
-        self.nExt = off
+                ins = e["ins"]
+                sz = e["size"]
+                n1 = sz[0] if len(sz) else 1
+                dist = P > 1 and len(sz) >= 1 and n1 >= 2 * P and len(ins) >= 4 * P
+                self.external[ins] = True
+                d = dict(name=e["varname"], entry=e["name"], size=sz, numel=len(ins), dist=dist)
+                if dist:
+                    # first dimension spread over the lanes: element (row, r) -> lane row % P,
+                    # per-lane slot r*K + row // P; rows padded to K*P with zeros
+                    K = -(-n1 // P)
+                    rest = len(ins) // n1
+                    d.update(n1=n1, K=K, rest=rest, off=doff, arr=len([x for x in self.inputs if x["dist"]]))
+                    for q, i in enumerate(ins):
+                        key = ("X", d["arr"], q // n1)
+                        self.dval[int(i)] = (key, q % n1)
+                        self.dvec_len[key] = n1
+                    doff += rest * K
+                else:
+                    self.ext_index[ins] = off + np.arange(len(ins))
+                    d.update(off=off)
+                    off += len(ins)
+                self.inputs.append(d)
+        self.nExt = off             # replicated inputs: doubles per instance in the SoA block S
+        self.nDist = doff           # distributed inputs: doubles per LANE in the block Sd
         out_needed = np.zeros(n + 1, dtype=bool)   # read by a get / copy source
         for e in T.gets:
             for o in e["outputs"]:
@@ -120,6 +154,10 @@ class Lowering:
             m = self._family_precheck(ins)
             if m is not None:
                 fam_members.append(m)
+        self.dfamilies = {}         # first member id -> DFamily
+        self.dreduce = {}           # sumprod/plus_sqr instruction id -> (nf, ns, factors)
+        if P > 1:
+            fam_members = self._classify_distributed(fam_members)
         # members (and their strided computed leaves) must live in indexable memory
         for m in fam_members:
             for i in m:
@@ -147,13 +185,15 @@ class Lowering:
                 if not self.external[i] and read_any[i]:
                     pslot[i] = k
                     k += 1
-            elif computed[i] and not self.local[i] and not self.inline[i]:
+            elif computed[i] and not self.local[i] and not self.inline[i] and i not in self.dval:
                 pslot[i] = k
                 k += 1
         self.pslot = pslot
         self.nPriv = k
         # ---- verify families against the final storage -----------------------------------------------------
         self._tree_cache = {}
+        if P > 1:
+            self.build_dfamilies()
         for m in fam_members:
             if self.in_family[m].any():
                 continue
@@ -171,6 +211,8 @@ class Lowering:
         j = int(j)
         if T.isload[j - 1]:
             return Leaf(j, "lit", -1, float(T.pars[T.parStart[j - 1]]))
+        if j in self.dval:
+            return Leaf(j, "dval", self.dval[j])
         if self.external[j]:
             return Leaf(j, "ext", int(self.ext_index[j]))
         if self.local[j]:
@@ -229,6 +271,174 @@ class Lowering:
                     return None
         return ins
 
+    # ---- distributed (wave-cooperative) classification --------------------------------------------
+    def _reduction_shape(self, q, dfam_of):
+        """If instruction q (I_sumprod / I_plus_sqr) sums over aligned distributed operands return
+        (nf, ns, [("d", vec) | ("r", instr id)] per factor), else None."""
+        T = self.T
+        typ, par, ops = T.instr(q)
+        if typ == I.I_sumprod:
+            nf, ns = int(par[0]), int(par[1])
+        elif typ == I.I_plus_sqr:
+            nf, ns = 1, len(ops)
+        else:
+            return None
+        if ns < 2 * self.P:
+            return None
+        facs = []
+        anyd = False
+        for p in range(nf):
+            o0 = int(ops[p])
+            if o0 in self.dval and (self.dval[o0][0][0] == "X" or self.dval[o0][0] in dfam_of):
+                vec = self.dval[o0][0]
+                for k in range(ns):
+                    o = int(ops[k * nf + p])
+                    if self.dval.get(o) != (vec, k):
+                        return None
+                facs.append(("d", vec))
+                anyd = True
+            else:
+                for k in range(ns):
+                    o = int(ops[k * nf + p])
+                    if o in self.dval:
+                        return None
+                    if o != o0:
+                        if not (T.isload[o - 1] and T.isload[o0 - 1]
+                                and T.pars[T.parStart[o - 1]] == T.pars[T.parStart[o0 - 1]]):
+                            return None
+                facs.append(("r", o0))
+        return (nf, ns, facs) if anyd else None
+
+    def _classify_distributed(self, fam_members):
+        """Decide which candidate families run distributed over the lanes.  A family is kept
+        distributed only if (a) every strided operand is element c of a distributed vector and every
+        other operand is replicated, and (b) every reader consumes member c aligned: as operand of
+        member c of another distributed family, or as term c of a reduction."""
+        T = self.T
+        P = self.P
+        cand = {}
+        for fid, m in enumerate(fam_members):
+            if len(m) >= 2 * P:
+                cand[fid] = m
+        readers = {}
+        for i in range(1, T.n + 1):
+            if not T.used[i] or T.group[i] == 0:
+                continue
+            for j in set(self.operands(i)):
+                readers.setdefault(j, []).append(i)
+        changed = True
+        while changed:
+            changed = False
+            # tentative distributed values of the surviving candidates
+            for k in [k for k, v in self.dval.items() if v[0][0] == "F"]:
+                del self.dval[k]
+            member_of = {}
+            for fid, m in cand.items():
+                for c, i in enumerate(m):
+                    self.dval[i] = (("F", fid), c)
+                    member_of[i] = (fid, c)
+            dfam_of = {("F", fid) for fid in cand}
+            for fid, m in list(cand.items()):
+                ok = True
+                sig = None
+                for c, i in enumerate(m):
+                    leaves = self._leaf_ids(i)
+                    row = []
+                    for j in leaves:
+                        if j in self.dval:
+                            vec, el = self.dval[j]
+                            if el != c or (vec[0] == "F" and vec not in dfam_of):
+                                ok = False
+                                break
+                            row.append(("d", vec))
+                        else:
+                            row.append(("r", j if not T.isload[j - 1] else ("lit", float(T.pars[T.parStart[j - 1]]))))
+                    if not ok:
+                        break
+                    if sig is None:
+                        sig = row
+                    elif row != sig:
+                        ok = False
+                        break
+                    # inlined reductions inside a distributed member are not supported
+                    if any(self._has_long_sum(i)):
+                        ok = False
+                        break
+                    if self.out_needed[i]:
+                        ok = False
+                        break
+                    for q in readers.get(i, []):
+                        # reader chain: q may be inlined into its consumer; what matters is q itself
+                        if q in member_of and member_of[q][1] == c and member_of[q][0] in cand:
+                            continue
+                        # inlined intermediate of a distributed member
+                        top = self._consumer_root(q, readers)
+                        if top in member_of and member_of[top][1] == c and member_of[top][0] in cand:
+                            continue
+                        if self._reduction_shape(q, dfam_of) is not None:
+                            continue
+                        ok = False
+                        break
+                    if not ok:
+                        break
+                if ok and not any(r[0] == "d" for r in (sig or [])):
+                    ok = False        # nothing distributed to gain from
+                if not ok:
+                    del cand[fid]
+                    changed = True
+        # final values
+        for k in [k for k, v in self.dval.items() if v[0][0] == "F"]:
+            del self.dval[k]
+        self._dcand = {}
+        for fid, m in cand.items():
+            for c, i in enumerate(m):
+                self.dval[i] = (("F", fid), c)
+            self.dvec_len[("F", fid)] = len(m)
+            self._dcand[fid] = m
+        dfam_of = {("F", fid) for fid in cand}
+        for q in range(1, T.n + 1):
+            if T.used[q] and T.group[q] > 0:
+                r = self._reduction_shape(q, dfam_of)
+                if r is not None:
+                    self.dreduce[q] = r
+        dm = set()
+        for m in cand.values():
+            dm.update(m)
+        # distributed members are not SSA temporaries nor memory-resident
+        for i in dm:
+            self.local[i] = False
+        return [m for fid, m in enumerate(fam_members) if fid not in cand]
+
+    def _has_long_sum(self, i):
+        for o in self.operands(i):
+            if self.inline[o]:
+                typ = int(self.T.types[o - 1])
+                if typ in (I.I_sumprod, I.I_plus_sqr) and len(self.operands(o)) >= 2 * self.P:
+                    yield True
+                yield from self._has_long_sum(int(o))
+
+    def _consumer_root(self, q, readers):
+        """follow single-consumer inlining chains up to the instruction that is actually emitted"""
+        while self.inline[q]:
+            r = readers.get(q, [])
+            if len(r) != 1:
+                break
+            q = r[0]
+        return q
+
+    def build_dfamilies(self):
+        """materialise DFamily objects (after storage assignment)"""
+        for fid, m in self._dcand.items():
+            t = self.tree(m[0])
+            leaves = []
+            for lf in self.flat_leaves(t):
+                if lf.kind == "dval":
+                    leaves.append(("d", lf.idx[0]))
+                else:
+                    leaves.append(("r", lf))
+            self.dfamilies[min(m)] = DFamily(fid, m, t, leaves)
+            self.in_family[m] = True
+
     def _leaf_ids(self, i):
         out = []
         for o in self.operands(i):
@@ -252,6 +462,8 @@ class Lowering:
     def _family_verify(self, members):
         trees = [self.tree(i) for i in members]
         L0 = self.flat_leaves(trees[0])
+        if any(lf.kind == "dval" for lf in L0):
+            return None           # reads distributed values: members are emitted one by one
         n = len(members)
         base = [lf.idx for lf in L0]
         delta = [0] * len(L0)

@@ -30,6 +30,12 @@ class TensCalcHipError(RuntimeError):
 
 
 def _bind(path):
+    # PyTorch-ROCm ships its own HIP runtime; load it first so the class library (linked against
+    # libamdhip64) binds to the same runtime instead of bringing a second one into the process.
+    try:
+        import torch  # noqa: F401
+    except ImportError:  # pragma: no cover - torch is plumbing, not a requirement of the C-ABI
+        pass
     if not os.path.exists(path):
         raise TensCalcHipError(f"solver class library {path} not found: build it first "
                                "(SolverSpec.build() / __graft_entry__.build())")

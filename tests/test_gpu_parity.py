@@ -136,10 +136,11 @@ def test_reference_c_surface_single_instance(libs, sls_spec, sls_tape_path):
     assert J.value == ref[0, 0] and np.array_equal(x, ref[0, 1:])
 
 
-def test_fast_build_within_stated_tolerance(libs, sls_spec, sls_tape_path):
-    B = 2048
+@pytest.mark.parametrize("variant", ["sls_fast", "sls_w8"])
+def test_fast_build_within_stated_tolerance(libs, sls_spec, sls_tape_path, variant):
+    B = 2048 + 5                            # ragged for the 8-instances-per-wave lowering too
     A, b, x0 = sls_batch(B, seed0=20000)
-    obj = _load(libs["sls_fast"], B)
+    obj = _load(libs[variant], B)
     _set(obj, A, b, x0)
     st, it, _ = obj.solve(**SOLVE_ARGS)
     J, x = obj.getOutputs()
