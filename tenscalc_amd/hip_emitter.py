@@ -44,7 +44,7 @@ _UNARY = {
     I.I_Datan: "1/(1+{0}*{0})", I.I_DDatan: "-2*{0}/(1+{0}*{0})/(1+{0}*{0})",
     I.I_srelu: "log(1+exp({0}))", I.I_dsrelu: "1/(1+exp(-{0}))",
     I.I_ddsrelu: "1/(2+exp(-{0})+exp({0}))", I.I_relu: "(({0}>0)?{0}:0.0)",
-    I.I_heaviside: "(({0}>0)?1.0:0.0)", I.I_inv: "1/{0}", I.I_minus_inv_sqr: "-1/({0}*{0})",
+    I.I_heaviside: "(({0}>0)?1.0:0.0)", I.I_inv: "TC_DIV(1.0,{0})", I.I_minus_inv_sqr: "-1/({0}*{0})",
     I.I_2_inv_cube: "2/({0}*{0}*{0})",
 }
 
@@ -65,9 +65,23 @@ from .lowering import Family, Leaf, Lowering, Node  # noqa: E402
 class Printer:
     """Expression printer for one Lowering (semantics: instructionsTableUTHash.c:950-1599)."""
 
-    def __init__(self, L, roll=True):
+    _DEN_POS = {I.I_div: 1, I.I_minus_dot_div: 0, I.I_plus_minus_dot_div: 1, I.I_inv: 0}
+
+    def __init__(self, L, roll=True, recip=False):
         self.L = L
         self.roll = roll
+        self.recip = recip          # x/d -> x*(1/d) with 1/d shared inside a group (opt-in: changes rounding)
+        self._rc = {}               # denominator instruction id -> name of its reciprocal in this group
+
+    def _den_leaves(self, t, acc):
+        """denominator leaves of every division in tree t"""
+        p = self._DEN_POS.get(t.typ)
+        if p is not None and isinstance(t.kids[p], Leaf) and t.kids[p].kind in ("priv", "tmp"):
+            acc.append(t.kids[p])
+        for k in t.kids:
+            if isinstance(k, Node):
+                self._den_leaves(k, acc)
+        return acc
 
     # leaf text ---------------------------------------------------------------------------------
     @staticmethod
@@ -164,6 +178,14 @@ class Printer:
                 r.append(self.leaf_text(k, base[j] if fam else None, delta[j] if fam else 0))
             else:
                 r.append("(" + self.expr(k, fam, pos) + ")")
+        p = self._DEN_POS.get(t.typ)
+        if fam is None and p is not None and isinstance(t.kids[p], Leaf) and t.kids[p].ins in self._rc:
+            rc = self._rc[t.kids[p].ins]
+            if t.typ == I.I_inv:
+                return rc
+            r2 = list(r)
+            r2[p] = "1.0"
+            return "(" + self.op_text(t.typ, t.par, r2).replace("TC_DIV", "TC_NUM") + ")*" + rc
         return self.op_text(t.typ, t.par, r)
 
     def _term_loop(self, t, tf):
@@ -228,7 +250,7 @@ class Printer:
                 e = f"({e})+({'+'.join(ln)})"
             return e
         if typ == I.I_div:
-            return f"{r[0]}/{r[1]}"
+            return f"TC_DIV({r[0]},{r[1]})"
         if typ in (I.I_minus_dot, I.I_minus_dot_div, I.I_plus_minus_dot, I.I_plus_minus_dot_div):
             skip = {I.I_minus_dot: 0, I.I_minus_dot_div: 1, I.I_plus_minus_dot: 1,
                     I.I_plus_minus_dot_div: 2}[typ]
@@ -237,10 +259,10 @@ class Printer:
             if typ == I.I_minus_dot:
                 return f"-({dot})"
             if typ == I.I_minus_dot_div:
-                return f"-({dot})/{r[0]}"
+                return f"TC_DIV(-({dot}),{r[0]})"
             if typ == I.I_plus_minus_dot:
                 return f"{r[0]}-({dot})"
-            return f"({r[0]}-({dot}))/{r[1]}"
+            return f"TC_DIV(({r[0]}-({dot})),{r[1]})"
         if typ == I.I_plus_sqr:
             return "+".join(f"{x}*{x}" for x in r)
         if typ == I.I_plus_abs:
@@ -276,10 +298,26 @@ class Printer:
         """HIP statements of dependency group g (1-based)"""
         L = self.L
         out = []
+        self._rc = {}
+        share = set()
+        if self.recip:
+            cnt = {}
+            for i in L.T.groups[g - 1]:
+                i = int(i)
+                if L.inline[i] or L.in_family[i]:
+                    continue
+                for lf in self._den_leaves(L.tree(i), []):
+                    cnt[lf.ins] = cnt.get(lf.ins, 0) + 1
+            share = {j for j, c_ in cnt.items() if c_ >= 2}
         for i in L.T.groups[g - 1]:
             i = int(i)
             if L.inline[i]:
                 continue
+            if share and not L.in_family[i]:
+                for lf in self._den_leaves(L.tree(i), []):
+                    if lf.ins in share and lf.ins not in self._rc:
+                        self._rc[lf.ins] = f"rc{lf.ins}"
+                        out.append(f"  const double rc{lf.ins} = TC_DIV(1.0,{self.leaf_text(lf)});\n")
             dfam = L.dfamilies.get(i)
             if dfam is not None:
                 out.append(self.dfamily_body(dfam))
@@ -288,7 +326,13 @@ class Printer:
             if fam is not None:
                 e = self.expr(fam.template, fam)
                 dst = f"{fam.dst0}+c_" if fam.ddst == 1 else f"{fam.dst0}+{fam.ddst}*c_"
-                out.append(f"  for (int c_ = 0; c_ < {fam.n}; c_++) {{ MM({dst}) = {e}; }}\n")
+                if L.P > 1:
+                    # the lanes sharing the instance split the members; LDS (in order within a
+                    # wave) makes every element visible to all of them afterwards
+                    out.append(f"  for (int c_ = lane; c_ < {fam.n}; c_ += TC_P) {{ MM({dst}) = {e}; }}\n"
+                               "  __builtin_amdgcn_wave_barrier();\n")
+                else:
+                    out.append(f"  for (int c_ = 0; c_ < {fam.n}; c_++) {{ MM({dst}) = {e}; }}\n")
                 continue
             if L.in_family[i]:
                 continue
@@ -318,7 +362,8 @@ def _mask(groups):
     return m
 
 
-def emit_class(spec, fp_contract="fast", block=64, stats=False, roll=True, min_waves=0, lanes=1):
+def emit_class(spec, fp_contract="fast", block=64, stats=False, roll=True, min_waves=0, lanes=1,
+               recip=False, fast_div=False):
     """Return the HIP source text of the solver class.
 
     lanes=1: one thread per problem instance (generic lowering, bit-exact with fp_contract='off').
@@ -330,7 +375,7 @@ def emit_class(spec, fp_contract="fast", block=64, stats=False, roll=True, min_w
     L = Lowering(T, getattr(spec, "code", None), roll=roll, lanes=lanes)
     if block % lanes:
         raise ValueError("block must be a multiple of lanes")
-    P = Printer(L, roll=roll)
+    P = Printer(L, roll=roll, recip=recip)
     cls = spec.classname
     nW = max(1, (T.nGroups + 63) // 64)
     w = []
@@ -375,7 +420,15 @@ def emit_class(spec, fp_contract="fast", block=64, stats=False, roll=True, min_w
              "  unsigned long long st[TC_NSTW];\n" + dmembers +
              "#ifdef TC_STATS\n  int nMinF;\n#endif\n};\n"
              f"#define SX(k) (S[(long)(k) * B])\n#define MM(k) {mm}\n"
-             "#define TC_UNPACK tc_mem m = c.m; tc_glob S = c.S; const long B = c.B; (void)m; (void)S; (void)B;\n"
+             "#define TC_UNPACK tc_mem m = c.m; tc_glob S = c.S; const long B = c.B; const int lane = c.lane; (void)m; (void)S; (void)B; (void)lane;\n"
+             "#define TC_NUM(x, d) (x)\n"
+             + ("// opt-in fast division: hardware reciprocal + two Newton steps + one residual correction\n"
+                "// (about 1 ulp, no denormal/overflow rescaling) instead of the correctly rounded sequence\n"
+                "static __device__ __forceinline__ double tc_fdiv(double x, double d) {\n"
+                "  double r = __builtin_amdgcn_rcp(d);\n  r = fma(fma(-d, r, 1.0), r, r);\n"
+                "  r = fma(fma(-d, r, 1.0), r, r);\n  const double q = x * r;\n"
+                "  return fma(fma(-d, q, x), r, q);\n}\n#define TC_DIV(x, d) tc_fdiv((x), (d))\n"
+                if fast_div else "#define TC_DIV(x, d) ((x) / (d))\n") +
              "static __device__ __forceinline__ double tc_min(double a, double x) { return (a > x) ? x : a; }\n"
              "static __device__ __forceinline__ double tc_max(double a, double x) { return (a < x) ? x : a; }\n"
              "// I_clp step: if (dx<0) { t=-x/dx; if (a>t) a=t; }  (instructionsTableUTHash.c:1315-1331)\n"
@@ -390,9 +443,9 @@ def emit_class(spec, fp_contract="fast", block=64, stats=False, roll=True, min_w
             w.append(P.group_body(g))
             w.append(f"}}\n#define TC_CALL_GRP{g} tc_grp{g}(c)\n")
         else:
-            w.append(f"static __device__ __noinline__ void tc_grp{g}(tc_mem m, tc_glob S, const long B) {{\n")
+            w.append(f"static __device__ __noinline__ void tc_grp{g}(tc_mem m, tc_glob S, const long B, const int lane) {{\n")
             w.append(P.group_body(g))
-            w.append(f"}}\n#define TC_CALL_GRP{g} tc_grp{g}(c.m, c.S, c.B)\n")
+            w.append(f"}}\n#define TC_CALL_GRP{g} tc_grp{g}(c.m, c.S, c.B, c.lane)\n")
     w.append("\n#define TC_NEED(g) do { if (!((c.st[((g)-1)>>6] >> (((g)-1)&63)) & 1ull)) { "
              "c.st[((g)-1)>>6] |= 1ull << (((g)-1)&63); TC_CALL_GRP##g; } } while (0)\n")
 
@@ -574,7 +627,8 @@ def class_header(spec):
 
 
 def build_class(spec, fp_contract="fast", arch="gfx950", opt="-O3", block=64, force=False,
-                outdir=None, stats=False, tag=None, extra_flags=(), roll=True, min_waves=0, lanes=1):
+                outdir=None, stats=False, tag=None, extra_flags=(), roll=True, min_waves=0, lanes=1,
+                recip=False, fast_div=False):
     """Emit <cls>.hip (+ <cls>.h, <cls>.tape) and compile lib<cls>.so with hipcc for gfx950.
     Mirrors the createGateway/compile step of cmex2optimizeCS.m:403-417."""
     from .tapeio import save_tape
@@ -583,7 +637,7 @@ def build_class(spec, fp_contract="fast", arch="gfx950", opt="-O3", block=64, fo
     os.makedirs(outdir, exist_ok=True)
     suffix = f"_{tag}" if tag else ""
     src, L = emit_class(spec, fp_contract=fp_contract, block=block, stats=stats, roll=roll,
-                        min_waves=min_waves, lanes=lanes)
+                        min_waves=min_waves, lanes=lanes, recip=recip, fast_div=fast_div)
     hip = os.path.join(outdir, f"{cls}{suffix}.hip")
     so = os.path.join(outdir, f"lib{cls}{suffix}.so")
     flags = [opt, f"--offload-arch={arch}", "-fPIC", "-shared", "-std=c++17",
