@@ -39,7 +39,9 @@ def main():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--batch", type=int, default=65536, help="instances per GPU")
-    ap.add_argument("--variant", default=os.environ.get("TC_BENCH_VARIANT", "strict"), choices=["strict", "fast", "w8", "w8r", "w8rf", "w4", "w16"])
+    ap.add_argument("--variant", default=os.environ.get("TC_BENCH_VARIANT", "w8"), choices=["strict", "fast", "w8"],
+                    help="strict: 1 thread/instance, -ffp-contract=off, bit-exact vs the oracle; fast: same with FMA; "
+                         "w8: 8 lanes/instance wave-cooperative lowering (default)")
     ap.add_argument("--cpu-sample", type=int, default=int(os.environ.get("TC_CPU_SAMPLE", "40000")))
     ap.add_argument("--no-cpu", action="store_true")
     args = ap.parse_args()
@@ -61,11 +63,7 @@ def main():
     from tenscalc_amd.problems.sls import SOLVE_ARGS, sls
     from tenscalc_amd.runtime import LAYOUT_BATCH_MINOR, HipSolver
     spec = sls(folder=g.GENERATED)
-    kw = {"strict": dict(fp_contract="off", tag="strict"), "fast": dict(fp_contract="fast"),
-          "w8": dict(fp_contract="fast", lanes=8, tag="w8"),
-          "w8r": dict(fp_contract="fast", lanes=8, tag="w8r", recip=True),
-          "w8rf": dict(fp_contract="fast", lanes=8, tag="w8rf", recip=True, fast_div=True), "w4": dict(fp_contract="fast", lanes=4, tag="w4"),
-          "w16": dict(fp_contract="fast", lanes=16, tag="w16")}[args.variant]
+    kw = dict(g.VARIANT_KW[args.variant])
     if os.environ.get("TC_EXPERIMENT"):          # e.g. TC_EXPERIMENT="min_waves=2,block=256" (tuning runs)
         for kv in os.environ["TC_EXPERIMENT"].split(","):
             k_, v_ = kv.split("=")

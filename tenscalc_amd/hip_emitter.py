@@ -449,13 +449,47 @@ def emit_class(spec, fp_contract="fast", block=64, stats=False, roll=True, min_w
     w.append("\n#define TC_NEED(g) do { if (!((c.st[((g)-1)>>6] >> (((g)-1)&63)) & 1ull)) { "
              "c.st[((g)-1)>>6] |= 1ull << (((g)-1)&63); TC_CALL_GRP##g; } } while (0)\n")
 
+    # Groups that use lane-distributed register state must be inlined wherever they are evaluated.
+    # To keep ONE copy of their code per invalidation point instead of one per reader they are
+    # PUSHED, not pulled: the set/copy that invalidates such a group re-evaluates it on the spot
+    # (after its ancestors), so every get/copy can assume it is clean and never tests it.
+    Dg = [g for g in range(1, T.nGroups + 1) if P.group_uses_distributed(g)]
+    gdeps = {g: set() for g in range(1, T.nGroups + 1)}
+    for g, members in enumerate(T.groups, 1):
+        for i in members:
+            for j in L.operands(int(i)):
+                gj = int(T.group[j])
+                if gj and gj != g:
+                    gdeps[g].add(gj)
+
+    def ancestors(g, acc):
+        for a in gdeps[g]:
+            if a not in acc:
+                acc.add(a)
+                ancestors(a, acc)
+        return acc
+
+    def push(children):
+        need = set()
+        for g in children:
+            if g in Dg:
+                need.add(g)
+                need |= ancestors(g, set())
+        return "".join(f"  TC_NEED({g});\n" for g in sorted(need))
+
+    internal_children = set()
+    for e in list(T.sets) + list(T.copies):
+        if not e.get("external"):
+            internal_children |= set(e["children"])
+    prologue_push = push([g for g in Dg if g not in internal_children])
+
     def inval(children):
         s = ""
         for wd in range(nW):
             m = sum(1 << ((g - 1) % 64) for g in children if (g - 1) // 64 == wd)
             if m:
                 s += f"  c.st[{wd}] &= ~0x{m:x}ull;\n"
-        return s
+        return s + push(children)
 
     # entry points ------------------------------------------------------------------------
     w.append("\n// ---- tape entry points (semantics: writeCfunctionpergroup.m:513-852)\n")
@@ -472,7 +506,8 @@ def emit_class(spec, fp_contract="fast", block=64, stats=False, roll=True, min_w
         args = ", ".join(f"double *y{k + 1}" for k in range(len(e["outputs"])))
         w.append(f"static __device__ __forceinline__ void {e['name']}(TcCtx &c, {args}) {{\n  TC_UNPACK\n")
         for g in e["parents"]:
-            w.append(f"  TC_NEED({g});\n")
+            if g not in Dg:
+                w.append(f"  TC_NEED({g});\n")
         for k, o in enumerate(e["outputs"]):
             for j, i in enumerate(o["ins"]):
                 w.append(f"  y{k + 1}[{j}] = {P.ref(i)};\n")
@@ -480,7 +515,8 @@ def emit_class(spec, fp_contract="fast", block=64, stats=False, roll=True, min_w
     for e in T.copies:
         w.append(f"static __device__ __forceinline__ void {e['name']}(TcCtx &c) {{\n  TC_UNPACK\n")
         for g in e["parents"]:
-            w.append(f"  TC_NEED({g});\n")
+            if g not in Dg:
+                w.append(f"  TC_NEED({g});\n")
         for d, s_ in zip(e["dst"], e["src"]):
             if L.external[d]:
                 raise NotImplementedError("copy into an external set")
@@ -508,6 +544,8 @@ def emit_class(spec, fp_contract="fast", block=64, stats=False, roll=True, min_w
             cnt = d["rest"] * d["K"]
             prologue += (f"  _Pragma(\"unroll\") for (int j = 0; j < {cnt}; j++) "
                          f"c.dX{d['arr']}[j] = Sd[((long)({d['off']} + j) * B + tid) * TC_P + c.lane];\n")
+    if prologue_push:
+        prologue += "  { TC_UNPACK\n" + prologue_push + "  }\n"
     outs = T.entry(f"{cls}_getOutputs")[2]["outputs"]
     w.append("extern \"C\" __global__ void TC_LAUNCH_BOUNDS\n"
              "tc_solve_kernel(const double *__restrict__ S, const double *__restrict__ Sd, double *__restrict__ O,\n"
