@@ -89,13 +89,13 @@ def main():
     O = torch.as_tensor(_DevArray(optr, (9, B), "<f8"), device=dev)
     ST = torch.as_tensor(_DevArray(sptr, (B,), "<i4"), device=dev)
     IT = torch.as_tensor(_DevArray(iptr, (B,), "<i4"), device=dev)
-    gathered = torch.empty((world, 10, B), dtype=torch.float64, device=dev) if world > 1 else None
+    from tenscalc_amd.sharding import gather_results, pack_results
+    gathered = torch.empty((world, 11, B), dtype=torch.float64, device=dev) if world > 1 else None
 
     def step():
         obj.solve_async(SOLVE_ARGS["mu0"], SOLVE_ARGS["maxIter"], SOLVE_ARGS["addEye2Hessian"], stream=stream)
-        if world > 1:   # gather results (J, x, status) on every rank -- the path's only exchange
-            pack = torch.cat([O, ST.to(torch.float64)[None]], 0)
-            dist.all_gather_into_tensor(gathered.view(world * 10, B), pack)
+        if world > 1:   # gather results (J, x, status, iter) on every rank -- the path's only exchange
+            gather_results(pack_results(O, ST, IT), world, out=gathered)
 
     for _ in range(args.warmup):
         step()
@@ -111,8 +111,7 @@ def main():
         obj.solve_async(SOLVE_ARGS["mu0"], SOLVE_ARGS["maxIter"], SOLVE_ARGS["addEye2Hessian"], stream=stream)
         evs[k][1].record()
         if world > 1:
-            pack = torch.cat([O, ST.to(torch.float64)[None]], 0)
-            dist.all_gather_into_tensor(gathered.view(world * 10, B), pack)
+            gather_results(pack_results(O, ST, IT), world, out=gathered)
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
@@ -144,8 +143,9 @@ def main():
                        "iter_median": float(np.median(it)), "iter_max": int(it.max()),
                        "sharding": "independent instances per rank, RCCL all_gather of results only"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBPS, "traffic": None,
+                         "frac": achieved / HBM_PEAK_GBPS, "traffic": measured_traffic(args.variant, B),
                          "kernel": "tc_solve_kernel", "kernel_ms_avg": kavg * 1e3,
+                         "algorithmic_bytes_per_launch": ALGO_BYTES_PER_SOLVE * B,
                          "algorithmic_bytes_per_solve": ALGO_BYTES_PER_SOLVE},
         }
         if not args.no_cpu and world >= 1:
@@ -155,6 +155,20 @@ def main():
         dist.barrier()
         dist.destroy_process_group()
     obj.close()
+
+
+def measured_traffic(variant, B):
+    """HBM bytes per launch of tc_solve_kernel from the committed rocprofv3 PMC passes
+    (profiles/traffic.json, written by scripts/profile_round.sh: separate --pmc FETCH_SIZE and
+    --pmc WRITE_SIZE runs, FETCH_SIZE doubled as MI355X_MICROARCH.md prescribes for gfx950).
+    None when no counter run exists for this exact variant and batch."""
+    try:
+        with open(os.path.join(ROOT, "profiles", "traffic.json")) as f:
+            t = json.load(f)
+        e = t.get("%s_B%d" % (variant, B))
+        return e["hbm_bytes_per_launch"] if e else None
+    except (OSError, ValueError, KeyError):
+        return None
 
 
 def cpu_baseline(spec, A, b, x0, sample, solve_args):
