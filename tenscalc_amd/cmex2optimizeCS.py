@@ -156,6 +156,9 @@ def cmex2optimizeCS(*, classname, objective, optimizationVariables, constraints=
     for fn, val in Tout.items():
         ph = Tvariable(fn + "_", val.size)
         outputExpressions = [substitute(o, ph, val) for o in outputExpressions]
+    # the reference returns structurally sparse <=2-D outputs as sparse mxArrays
+    # (writeCfunctionpergroup.m:590-605,716-727); the batched interface always returns dense arrays
+    outputExpressions = [tc.full(o) for o in outputExpressions]
     code.declareGet(outputExpressions, f"{classname}_getOutputs", list(outputNames))
 
     defines = dict(

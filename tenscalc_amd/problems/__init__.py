@@ -1,3 +1,4 @@
 """Problem statements of the BASELINE configs, written against the
 reference's own example scripts."""
 from .sls import sls, sls_data  # noqa: F401
+from .mpc_dcmotor import mpc_dcmotor, dcmotor_data  # noqa: F401

@@ -221,3 +221,31 @@ def test_full_batch_properties(libs):
     x3 = obj2.getOutputs()[1].reshape(B, 8)
     p = perm.cpu().numpy()
     assert np.array_equal(it3, it[p]) and np.array_equal(x3, x[p])
+
+
+def test_dcmotor_strict_bit_exact_vs_oracle(libs, tmp_path):
+    """BASELINE configs[3] problem (equality + inequality constraints, 323x323 KKT, second LDL for
+    initDualEqX__) through the generic one-thread-per-instance lowering: bit-identical to the oracle."""
+    import __graft_entry__ as g
+    from tenscalc_amd.problems.mpc_dcmotor import SOLVE_ARGS as DC_ARGS, dcmotor_data, mpc_dcmotor
+    from tenscalc_amd.tapeio import save_tape
+    from oracle.tc_oracle import Oracle
+    spec = mpc_dcmotor(folder=g.GENERATED)
+    tape = str(tmp_path / "dc.tape")
+    save_tape(spec.tape, tape)
+    B = 200
+    data = [dcmotor_data(1000 + k) for k in range(B)]
+    obj = _load(libs["dcmotor_strict"], B)
+    names = [n for n, _ in spec.parameters + spec.variables]
+    stacked = {n: np.stack([np.asarray(d[n], dtype=float).reshape(-1, order="F") for d in data]) for n in names}
+    for n in names:
+        obj.set(n, stacked[n])
+    st, it, _ = obj.solve(**DC_ARGS)
+    outs = obj.getOutputs()
+    c = spec.classname
+    o = Oracle(tape)
+    ref, rst, rit = o.solve_batch({f"{c}_set_{n}": stacked[n] for n in names}, c + "_getOutputs", B,
+                                  mu0=DC_ARGS["mu0"], maxIter=DC_ARGS["maxIter"])
+    assert np.array_equal(st, rst) and np.array_equal(it, rit) and (st == 0).all()
+    got = np.concatenate([a.reshape(B, -1) for a in outs], axis=1)
+    assert np.array_equal(got, ref)
