@@ -35,8 +35,11 @@ def test_reference_symbols_exported(libs):
         L = ctypes.CDLL(so, mode=ctypes.RTLD_LOCAL)
         L.tc_classname.restype = ctypes.c_char_p
         cls = L.tc_classname().decode()
+        L.tc_input_name.restype = ctypes.c_char_p
+        inputs = [L.tc_input_name(k).decode() for k in range(L.tc_num_inputs())]
+        assert len(inputs) >= 3
         # writeCfunctionpergroup.m:524,607-635; ipmPD_CSsolver.c:132 (unprefixed name)
-        for n in [f"{cls}_set_A", f"{cls}_set_b", f"{cls}_set_x", f"{cls}_getOutputs", "ipmPD_CSsolver"]:
+        for n in [f"{cls}_set_{i}" for i in inputs] + [f"{cls}_getOutputs", "ipmPD_CSsolver"]:
             assert hasattr(L, n), f"{tag}: {n} missing"
 
 
