@@ -44,3 +44,9 @@ def tsDerivative2(x, Ts):
     ix = tuple(range(1, x.ndim)) + (-1,)
     Ts = tc.toT(Ts)
     return tc.tprod(x, ix, tc.Tconstant(D), (-1, x.ndim)) / (Ts * Ts)
+
+
+def tsCross(x1, x2):
+    """column-wise cross product of two 3xT series (lib/tsCross.m:41-45)"""
+    x1, x2 = tc.toT(x1), tc.toT(x2)
+    return (tc.times(x1[[1, 2, 0], :], x2[[2, 0, 1], :]) - tc.times(x1[[2, 0, 1], :], x2[[1, 2, 0], :]))

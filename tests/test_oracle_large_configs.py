@@ -1,0 +1,66 @@
+"""CPU: BASELINE configs[2] (l1l2estimationCS, 1792x1792 KKT, scaleCost) and configs[4]
+(mpc_quadcopter, 1406x1406 KKT, sqrt/rdivide derivatives) at the tape + oracle level: sizes match
+SURVEY.md 8a, the solver converges, and the restated Newton loop agrees bit-for-bit with the
+reference's ipmPD_CSsolver.c.  (Their HIP lowering is a later-round item: DESIGN.md 9.)"""
+import numpy as np
+import pytest
+
+
+def _run(spec, data, args, tag, tmp_path, seeds):
+    from tenscalc_amd.tapeio import save_tape
+    from oracle.tc_oracle import Oracle, ReferenceLoopOracle
+    tape = str(tmp_path / (tag + ".tape"))
+    save_tape(spec.tape, tape)
+    o = Oracle(tape)
+    try:
+        ro = ReferenceLoopOracle(tape, tag, spec.defines)
+    except (FileNotFoundError, OSError):
+        ro = None
+    c = spec.classname
+    out = []
+    for seed in seeds:
+        d = data(seed)
+        r = []
+        for q in [o] + ([ro] if ro else []):
+            for nm, _ in spec.parameters + spec.variables:
+                q.set(f"{c}_set_{nm}", d[nm])
+            st, it = q.solve(args["mu0"], args["maxIter"], -1, args["addEye2Hessian"])
+            r.append((st, it, q.get(c + "_getOutputs")))
+        if ro:
+            assert r[0][:2] == r[1][:2] and np.array_equal(r[0][2], r[1][2], equal_nan=True)
+        out.append((d, r[0]))
+    return out
+
+
+def test_l1l2(native_built, tmp_path):
+    from tenscalc_amd.problems.l1l2 import SOLVE_ARGS, l1l2, l1l2_data
+    spec = l1l2(folder=str(tmp_path))
+    d = spec.defines
+    assert (d["nU"], d["nG"], d["nF"], d["scaleCost"]) == (996, 0, 796, 1)     # KKT 1792
+    assert spec.tape.ldl_stats[0]["n"] == 1792 and spec.tape.ldl_stats[0]["nonsym"] == 0
+    for data, (st, it, y) in _run(spec, l1l2_data, SOLVE_ARGS, "l1l2", tmp_path, (1, 2)):
+        assert st == 0 and it < 60
+        pos, n1, n1abs = y[1:201], y[201:401], y[599:799]
+        assert (np.abs(n1) <= n1abs + 1e-6).all()                         # |noise1| <= noise1abs
+        assert np.abs(pos - data["truePosition"]).mean() < 1.0            # robust to the 10% outliers
+
+
+def test_mpc_quadcopter(native_built, tmp_path):
+    from tenscalc_amd.problems.mpc_quadcopter import SOLVE_ARGS, mpc_quadcopter, quadcopter_data
+    spec = mpc_quadcopter(folder=str(tmp_path))
+    d = spec.defines
+    assert (d["nU"], d["nG"], d["nF"]) == (700, 406, 300)                 # KKT 1406
+    for data, (st, it, y) in _run(spec, quadcopter_data, SOLVE_ARGS, "quadcopter", tmp_path, (0, 2)):
+        assert st == 0 and it < 200
+        names = [n for n, _ in spec.outputs]
+        sizes = [int(np.prod(s)) if len(s) else 1 for _, s in spec.outputs]
+        off = np.cumsum([0] + sizes)
+        got = {n: y[off[i]:off[i + 1]] for i, n in enumerate(names)}
+        m = got["m_thrust"]
+        assert (m >= 5 - 1e-6).all() and (m <= 20 + 1e-6).all()           # thrust limits
+        u = got["u"].reshape((3, 100), order="F")
+        np.testing.assert_allclose(m, np.sqrt((u ** 2).sum(0)), rtol=1e-12)
+        R3 = got["R_ib3"].reshape((3, 100), order="F")
+        np.testing.assert_allclose((R3 ** 2).sum(0), 1.0, rtol=1e-12)      # unit thrust direction
+        p = got["p"].reshape((3, 100), order="F")
+        assert (p[2] <= .1 + 1e-6).all()                                    # altitude constraint
