@@ -90,6 +90,12 @@ int tc_probe(tc_solver_t *h, const char *getName, double mu0, const double *addE
              double *out, int64_t B);
 int64_t tc_probe_numel(const char *getName);
 
+/* ---- diagnostics of builds made with stats=True (TC_STATS): rows [0,G) wall cycles spent in
+ * dependency group g, [G,2G) evaluation counts, 2G total kernel cycles, 2G+1 getMinF_s__ trials;
+ * out is [tc_stats_rows()][B].  All zero for ordinary builds. */
+int64_t tc_stats_rows(void);
+int tc_get_stats(tc_solver_t *h, double *out);
+
 #ifdef __cplusplus
 }
 #endif

@@ -85,7 +85,7 @@ class Printer:
 
     # leaf text ---------------------------------------------------------------------------------
     @staticmethod
-    def leaf_text(lf, base=None, dc=0, dk=0):
+    def leaf_text(lf, base=None, dc=0, dk=0, var="c_"):
         if lf.kind == "lit":
             return _lit(lf.val)
         if lf.kind == "tmp":
@@ -93,7 +93,7 @@ class Printer:
         b = lf.idx if base is None else base
         ix = str(b)
         if dc:
-            ix += f"+{dc}*c_" if dc != 1 else "+c_"
+            ix += f"+({dc})*{var}" if dc != 1 else f"+{var}"
         if dk:
             ix += f"+{dk}*k_" if dk != 1 else "+k_"
         return f"SX({ix})" if lf.kind == "ext" else f"MM({ix})"
@@ -150,6 +150,109 @@ class Printer:
                 r.append("(" + self._dexpr(kid, f, k, pos) + ")")
         return self.op_text(t.typ, t.par, r)
 
+    # reductions over REPLICATED operands held in consecutive LDS slots: the P lanes of the instance
+    # each take every P-th operand and combine with a DPP butterfly (sum / min / max)
+    _LANE_RED = {I.I_min: ("min", 1), I.I_min0: ("min", 1), I.I_max: ("max", 1), I.I_max0: ("max", 1),
+                 I.I_max_abs: ("max", 1), I.I_clp: ("min", 2), I.I_plus_sqr: ("add", 1), I.I_plus_abs: ("add", 1),
+                 I.I_sumprod: ("add", 0), I.I_sum: ("add", 1)}
+
+    def _col_text(self, kids):
+        """text of one operand column over a run of terms (index variable j_), or None if the run
+        is not affine"""
+        L = self.L
+        k0 = kids[0]
+        n = len(kids)
+        if isinstance(k0, Node):
+            if not all(isinstance(x, Node) for x in kids):
+                return None
+            bd = L.affine_trees(kids)
+            if bd is None:
+                return None
+            return "(" + self.expr(k0, Family([], k0, bd[0], bd[1], 0, 0, var="j_"), [0]) + ")"
+        if not all(isinstance(x, Leaf) and x.kind == k0.kind for x in kids):
+            return None
+        if k0.kind == "lit":
+            return _lit(k0.val) if all(x.val == k0.val for x in kids) else None
+        if k0.kind == "tmp":
+            return f"t{k0.idx}" if all(x.idx == k0.idx for x in kids) else None
+        if k0.kind != "priv":
+            return None
+        d = kids[1].idx - k0.idx if n > 1 else 0
+        if any(x.idx != k0.idx + d * j for j, x in enumerate(kids)):
+            return None
+        return f"MM({k0.idx}+({d})*j_)" if d else f"MM({k0.idx})"
+
+    def lane_reduction(self, t):
+        """min/max/clp/sum over many operands held in LDS: split the operand list into maximal
+        affine runs, let the P lanes of the instance take every P-th operand of each run, combine
+        with one DPP butterfly; operands outside any run are folded in afterwards."""
+        L = self.L
+        if L.P <= 1 or t.typ not in self._LANE_RED:
+            return None
+        kind, w = self._LANE_RED[t.typ]
+        if t.typ == I.I_sumprod:
+            w = int(t.par[0])
+        n = len(t.kids) // w
+        if n < L.P or len(t.kids) != n * w:
+            return None
+        if t.typ == I.I_sum and any(p != t.par[0] for p in t.par):
+            return None
+        ty = t.typ
+
+        def step(cols):
+            if ty in (I.I_min, I.I_min0):
+                return f"a_ = tc_op_min(a_, {cols[0]});"
+            if ty in (I.I_max, I.I_max0):
+                return f"a_ = tc_op_max(a_, {cols[0]});"
+            if ty == I.I_max_abs:
+                return f"a_ = tc_op_max(a_, fabs({cols[0]}));"
+            if ty == I.I_clp:
+                return f"a_ = tc_clp(a_, {cols[0]}, {cols[1]});"
+            if ty == I.I_plus_sqr:
+                return f"a_ = a_ + {cols[0]}*{cols[0]};"
+            if ty == I.I_plus_abs:
+                return f"a_ = a_ + fabs({cols[0]});"
+            if ty == I.I_sum:
+                return f"a_ = a_ + {cols[0]};"
+            return "a_ = a_ + " + "*".join(cols) + ";"
+
+        minrun = max(2, L.P // 2)
+        runs, singles = [], []
+        k0 = 0
+        while k0 < n:
+            best = None
+            k1 = min(n, k0 + minrun)
+            while k1 <= n:
+                cols = [self._col_text([t.kids[k * w + p] for k in range(k0, k1)]) for p in range(w)]
+                if any(c_ is None for c_ in cols) or (k1 - k0 > 1 and not any("j_" in c_ for c_ in cols)):
+                    break
+                best = (k1, cols)
+                k1 += 1
+            if best is None:
+                singles.append(k0)
+                k0 += 1
+            else:
+                runs.append((k0, best[0], best[1]))
+                k0 = best[0]
+        if not runs or sum(k1 - k0 for k0, k1, _ in runs) < L.P:
+            return None
+        init = {I.I_min: "DBL_MAX", I.I_max: "-DBL_MAX", I.I_clp: "DBL_MAX"}.get(ty, "0.0")
+        red = {"add": "tc_allreduce", "min": "tc_allreduce_min", "max": "tc_allreduce_max"}[kind]
+        body = f"({{ double a_ = {init};"
+        for k0, k1, cols in runs:
+            body += f" for (int j_ = lane; j_ < {k1 - k0}; j_ += TC_P) {{ {step(cols)} }}"
+        body += f" a_ = {red}(a_);"
+        for k in singles:
+            cols = []
+            for p in range(w):
+                kid = t.kids[k * w + p]
+                cols.append(self.leaf_text(kid) if isinstance(kid, Leaf) else "(" + self.expr(kid) + ")")
+            body += " " + step(cols)
+        body += " a_; })"
+        if ty == I.I_sum and t.par[0] < 0:
+            body = "-" + body
+        return body
+
     def expr(self, t, fam=None, pos=None):
         """C expression of tree t.  fam: Family (leaf index = base+delta*c_) or None.
         pos: running index into the flattened leaf list (list of one int)."""
@@ -159,6 +262,11 @@ class Printer:
         if t.ins in L.dreduce:
             pos[0] += len(t.kids)
             return self.reduction(t)
+        if fam is None and L.P > 1:
+            lr = self.lane_reduction(t)
+            if lr is not None:
+                pos[0] += len(t.kids)
+                return lr
         base = fam.base if fam else None
         delta = fam.delta if fam else None
         # V2: long sums rolled over the term index k_
@@ -175,7 +283,8 @@ class Printer:
             if isinstance(k, Leaf):
                 j = pos[0]
                 pos[0] += 1
-                r.append(self.leaf_text(k, base[j] if fam else None, delta[j] if fam else 0))
+                r.append(self.leaf_text(k, base[j] if fam else None, delta[j] if fam else 0,
+                                        var=fam.var if fam else "c_"))
             else:
                 r.append("(" + self.expr(k, fam, pos) + ")")
         p = self._DEN_POS.get(t.typ)
@@ -418,7 +527,7 @@ def emit_class(spec, fp_contract="fast", block=64, stats=False, roll=True, min_w
              f"typedef {mem_t} tc_mem;\n"
              "struct TcCtx {\n  tc_mem m;\n  tc_glob S;\n  long B;\n  int lane;\n"
              "  unsigned long long st[TC_NSTW];\n" + dmembers +
-             "#ifdef TC_STATS\n  int nMinF;\n#endif\n};\n"
+             "#ifdef TC_STATS\n  int nMinF;\n  long long cyc[TC_NGROUPS];\n  int cnt[TC_NGROUPS];\n#endif\n};\n"
              f"#define SX(k) (S[(long)(k) * B])\n#define MM(k) {mm}\n"
              "#define TC_UNPACK tc_mem m = c.m; tc_glob S = c.S; const long B = c.B; const int lane = c.lane; (void)m; (void)S; (void)B; (void)lane;\n"
              "#define TC_NUM(x, d) (x)\n"
@@ -446,8 +555,12 @@ def emit_class(spec, fp_contract="fast", block=64, stats=False, roll=True, min_w
             w.append(f"static __device__ __noinline__ void tc_grp{g}(tc_mem m, tc_glob S, const long B, const int lane) {{\n")
             w.append(P.group_body(g))
             w.append(f"}}\n#define TC_CALL_GRP{g} tc_grp{g}(c.m, c.S, c.B, c.lane)\n")
-    w.append("\n#define TC_NEED(g) do { if (!((c.st[((g)-1)>>6] >> (((g)-1)&63)) & 1ull)) { "
-             "c.st[((g)-1)>>6] |= 1ull << (((g)-1)&63); TC_CALL_GRP##g; } } while (0)\n")
+    w.append("\n#ifndef TC_STATS\n#define TC_NEED(g) do { if (!((c.st[((g)-1)>>6] >> (((g)-1)&63)) & 1ull)) { "
+             "c.st[((g)-1)>>6] |= 1ull << (((g)-1)&63); TC_CALL_GRP##g; } } while (0)\n"
+             "#else  // diagnostic build: wall cycles (s_memtime) and call count per dependency group\n"
+             "#define TC_NEED(g) do { if (!((c.st[((g)-1)>>6] >> (((g)-1)&63)) & 1ull)) { "
+             "c.st[((g)-1)>>6] |= 1ull << (((g)-1)&63); const long long t0_ = clock64(); TC_CALL_GRP##g; "
+             "c.cyc[(g)-1] += clock64() - t0_; c.cnt[(g)-1]++; } } while (0)\n#endif\n")
 
     # Groups that use lane-distributed register state must be inlined wherever they are evaluated.
     # To keep ONE copy of their code per invalidation point instead of one per reader they are
@@ -538,7 +651,8 @@ def emit_class(spec, fp_contract="fast", block=64, stats=False, roll=True, min_w
                 "#else\n  __shared__ double tc_lds_m[TC_NM * TC_G];\n  c.m = (tc_lds)&tc_lds_m[threadIdx.x / TC_P];\n#endif\n"
                 "  c.lane = (int)(t_ % TC_P);\n  c.S = (tc_glob)(S + tid);\n  c.B = B;\n"
                 "  for (int k = 0; k < TC_NSTW; k++) c.st[k] = 0;\n"
-                "#ifdef TC_STATS\n  c.nMinF = 0;\n#endif\n")
+                "#ifdef TC_STATS\n  c.nMinF = 0;\n  for (int k = 0; k < TC_NGROUPS; k++) { c.cyc[k] = 0; c.cnt[k] = 0; }\n"
+                "  const long long tstart_ = clock64();\n#endif\n")
     for d in L.inputs:
         if d["dist"]:
             cnt = d["rest"] * d["K"]
@@ -550,7 +664,7 @@ def emit_class(spec, fp_contract="fast", block=64, stats=False, roll=True, min_w
     w.append("extern \"C\" __global__ void TC_LAUNCH_BOUNDS\n"
              "tc_solve_kernel(const double *__restrict__ S, const double *__restrict__ Sd, double *__restrict__ O,\n"
              "                int *__restrict__ status, int *__restrict__ iter, double mu0, int maxIter, double ae0,\n"
-             "                double ae1, long B) {\n" + prologue +
+             "                double ae1, long B, double *__restrict__ dbg) {\n" + prologue +
              "  int st = 0, it = 0;\n"
              "  ipmPD_CSsolver(c, mu0, maxIter, ae0, ae1, &st, &it);\n")
     for k, o in enumerate(outs):
@@ -564,7 +678,11 @@ def emit_class(spec, fp_contract="fast", block=64, stats=False, roll=True, min_w
         w.append(f"  for (int j = 0; j < {n_}; j++) O[(long)({off} + j) * B + tid] = y{k + 1}[j];\n")
         out_meta.append((o["name"], o["size"], n_, off))
         off += n_
-    w.append("  status[tid] = st;\n  iter[tid] = it;\n}\n\n")
+    w.append("  status[tid] = st;\n  iter[tid] = it;\n"
+             "#ifdef TC_STATS\n  if (dbg) {\n    for (int k = 0; k < TC_NGROUPS; k++) {\n"
+             "      dbg[(long)k * B + tid] = (double)c.cyc[k];\n      dbg[(long)(TC_NGROUPS + k) * B + tid] = (double)c.cnt[k];\n    }\n"
+             "    dbg[(long)(2 * TC_NGROUPS) * B + tid] = (double)(clock64() - tstart_);\n"
+             "    dbg[(long)(2 * TC_NGROUPS + 1) * B + tid] = (double)c.nMinF;\n  }\n#endif\n}\n\n")
     # probe kernel: init sequence then one get
     w.append("extern \"C\" __global__ void __launch_bounds__(TC_BLOCK)\n"
              "tc_probe_kernel(const double *__restrict__ S, const double *__restrict__ Sd, double *__restrict__ out,\n"

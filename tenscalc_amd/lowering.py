@@ -43,10 +43,11 @@ class Family:
     """V1 element family: members (instruction ids) share one template tree; leaf j of member c is
     at index base[j] + delta[j]*c; destination private slot dst0 + ddst*c."""
 
-    def __init__(self, members, template, base, delta, dst0, ddst):
+    def __init__(self, members, template, base, delta, dst0, ddst, var="c_"):
         self.members, self.template = members, template
         self.base, self.delta, self.dst0, self.ddst = base, delta, dst0, ddst
         self.n = len(members)
+        self.var = var              # name of the loop index in the printed code
 
 
 class DFamily:
@@ -458,6 +459,43 @@ class Lowering:
             else:
                 Lowering.flat_leaves(k, acc)
         return acc
+
+    def affine_trees(self, trees):
+        """(base, delta) per flattened leaf if the trees share one structure and every leaf index is
+        an arithmetic progression over the list, else None"""
+        def sig(t):
+            return (t.typ, t.par, tuple(sig(k) if isinstance(k, Node) else "L" for k in t.kids))
+        s0 = sig(trees[0])
+        L0 = self.flat_leaves(trees[0])
+        if any(lf.kind == "dval" for lf in L0):
+            return None
+        n = len(trees)
+        base = [lf.idx for lf in L0]
+        delta = [0] * len(L0)
+        if n > 1:
+            L1 = self.flat_leaves(trees[1])
+            if len(L1) != len(L0):
+                return None
+            delta = [(b.idx - a.idx) if a.kind in ("priv", "ext") and b.kind == a.kind else 0
+                     for a, b in zip(L0, L1)]
+        for c, t in enumerate(trees):
+            if c and sig(t) != s0:
+                return None
+            Lc = self.flat_leaves(t)
+            if len(Lc) != len(L0):
+                return None
+            for j, lf in enumerate(Lc):
+                if lf.kind != L0[j].kind:
+                    return None
+                if lf.kind == "lit":
+                    if lf.val != L0[j].val:
+                        return None
+                elif lf.kind == "tmp":
+                    if lf.idx != L0[j].idx:
+                        return None
+                elif lf.idx != base[j] + delta[j] * c:
+                    return None
+        return base, delta
 
     def _family_verify(self, members):
         trees = [self.tree(i) for i in members]

@@ -72,6 +72,8 @@ def _bind(path):
                                 c.POINTER(c.c_void_p)]
     L.tc_synchronize.argtypes = [c.c_void_p]
     L.tc_probe.argtypes = [c.c_void_p, c.c_char_p, c.c_double, _dp, _dp, c.c_int64]
+    L.tc_stats_rows.restype = c.c_int64
+    L.tc_get_stats.argtypes = [c.c_void_p, _dp]
     L.tc_probe_numel.restype = c.c_int64
     L.tc_probe_numel.argtypes = [c.c_char_p]
     return L
@@ -197,6 +199,13 @@ class HipSolver:
         o, s, i = ctypes.c_void_p(), ctypes.c_void_p(), ctypes.c_void_p()
         self._check(self._L.tc_get_device(self._h, ctypes.byref(o), ctypes.byref(s), ctypes.byref(i)))
         return o.value, s.value, i.value
+
+    def stats(self):
+        """diagnostic (stats=True) builds: per-group cycles/calls -> array [rows, B]"""
+        rows = int(self._L.tc_stats_rows())
+        out = np.zeros((rows, self.B))
+        self._check(self._L.tc_get_stats(self._h, out.ctypes.data_as(_dp)))
+        return out
 
     def probe(self, get_name, mu0=1.0, addEye2Hessian=(1e-9, 1e-9)):
         """evaluate a tape get entry point after the solver's initialisation sequence -> [B, numel]"""
