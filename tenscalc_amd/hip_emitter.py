@@ -472,7 +472,7 @@ def _mask(groups):
 
 
 def emit_class(spec, fp_contract="fast", block=64, stats=False, roll=True, min_waves=0, lanes=1,
-               recip=False, fast_div=False):
+               recip=False, fast_div=False, inline_max=0):
     """Return the HIP source text of the solver class.
 
     lanes=1: one thread per problem instance (generic lowering, bit-exact with fp_contract='off').
@@ -547,7 +547,8 @@ def emit_class(spec, fp_contract="fast", block=64, stats=False, roll=True, min_w
     # dependency groups ------------------------------------------------------------------
     for g, members in enumerate(T.groups, 1):
         w.append(f"// group {g}: {len(members)} instructions, {int(T.flops[g].sum())} flops\n")
-        if P.group_uses_distributed(g):
+        if P.group_uses_distributed(g) or len(members) <= inline_max:
+            # small groups are inlined at their call sites: a call costs more than they do
             w.append(f"static __device__ __forceinline__ void tc_grp{g}(TcCtx &c) {{\n  TC_UNPACK\n")
             w.append(P.group_body(g))
             w.append(f"}}\n#define TC_CALL_GRP{g} tc_grp{g}(c)\n")
@@ -784,7 +785,7 @@ def class_header(spec):
 
 def build_class(spec, fp_contract="fast", arch="gfx950", opt="-O3", block=64, force=False,
                 outdir=None, stats=False, tag=None, extra_flags=(), roll=True, min_waves=0, lanes=1,
-                recip=False, fast_div=False):
+                recip=False, fast_div=False, inline_max=0):
     """Emit <cls>.hip (+ <cls>.h, <cls>.tape) and compile lib<cls>.so with hipcc for gfx950.
     Mirrors the createGateway/compile step of cmex2optimizeCS.m:403-417."""
     from .tapeio import save_tape
@@ -793,7 +794,7 @@ def build_class(spec, fp_contract="fast", arch="gfx950", opt="-O3", block=64, fo
     os.makedirs(outdir, exist_ok=True)
     suffix = f"_{tag}" if tag else ""
     src, L = emit_class(spec, fp_contract=fp_contract, block=block, stats=stats, roll=roll,
-                        min_waves=min_waves, lanes=lanes, recip=recip, fast_div=fast_div)
+                        min_waves=min_waves, lanes=lanes, recip=recip, fast_div=fast_div, inline_max=inline_max)
     hip = os.path.join(outdir, f"{cls}{suffix}.hip")
     so = os.path.join(outdir, f"lib{cls}{suffix}.so")
     flags = [opt, f"--offload-arch={arch}", "-fPIC", "-shared", "-std=c++17",
