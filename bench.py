@@ -42,7 +42,7 @@ def main():
     ap.add_argument("--variant", default=os.environ.get("TC_BENCH_VARIANT", "w8"), choices=["strict", "fast", "w8"],
                     help="strict: 1 thread/instance, -ffp-contract=off, bit-exact vs the oracle; fast: same with FMA; "
                          "w8: 8 lanes/instance wave-cooperative lowering (default)")
-    ap.add_argument("--cpu-sample", type=int, default=int(os.environ.get("TC_CPU_SAMPLE", "40000")))
+    ap.add_argument("--cpu-sample", type=int, default=int(os.environ.get("TC_CPU_SAMPLE", "65536")))
     ap.add_argument("--no-cpu", action="store_true")
     args = ap.parse_args()
 
@@ -172,28 +172,38 @@ def measured_traffic(variant, B):
 
 
 def cpu_baseline(spec, A, b, x0, sample, solve_args):
-    """The oracle (CPU restatement of the reference path, kind "port") timed on ONE host core over
-    the first `sample` instances of the same workload."""
+    """The CPU restatement of the reference path timed on ONE host core over the first `sample`
+    instances of the same workload (kind "port").  Preferred: the generated-C twin (oracle/c_emitter.py:
+    the tape as reference-style straight-line C + the reference's ipmPD_CSsolver.c, gcc -O1, prebuilt
+    in the development container); fallback: the tape interpreter oracle/tc_oracle.c."""
     import numpy as np
-    from oracle.tc_oracle import Oracle
     import __graft_entry__ as g
-    tape = os.path.join(g.GENERATED, "@" + spec.classname, spec.classname + ".tape")
-    o = Oracle(tape)
     c = spec.classname
     n = min(sample, A.shape[1])
     Ah = np.ascontiguousarray(A[:, :n].t().cpu().numpy())
     bh = np.ascontiguousarray(b[:, :n].t().cpu().numpy())
     xh = np.ascontiguousarray(x0[:, :n].t().cpu().numpy())
-    o.solve_batch({c + "_set_A": Ah[:64], c + "_set_b": bh[:64], c + "_set_x": xh[:64]}, c + "_getOutputs", 64,
-                  mu0=solve_args["mu0"], maxIter=solve_args["maxIter"])          # warm-up
-    t0 = time.perf_counter()
-    out, st, it = o.solve_batch({c + "_set_A": Ah, c + "_set_b": bh, c + "_set_x": xh}, c + "_getOutputs", n,
-                                mu0=solve_args["mu0"], maxIter=solve_args["maxIter"])
-    dt = time.perf_counter() - t0
+    try:
+        from oracle.c_emitter import CpuTwin
+        tw = CpuTwin(spec)
+        tw.solve_batch({"A": Ah[:64], "b": bh[:64], "x": xh[:64]}, 64, mu0=solve_args["mu0"], maxIter=solve_args["maxIter"])
+        t0 = time.perf_counter()
+        out, st, it = tw.solve_batch({"A": Ah, "b": bh, "x": xh}, n, mu0=solve_args["mu0"], maxIter=solve_args["maxIter"])
+        dt = time.perf_counter() - t0
+        what = ("generated-C twin of the tape (oracle/c_emitter.py) + reference lib/ipmPD_CSsolver.c, gcc -O1, "
+                "prebuilt oracle/_ref/lib%s_cpu.so" % c)
+    except (FileNotFoundError, OSError):
+        from oracle.tc_oracle import Oracle
+        o = Oracle(os.path.join(g.GENERATED, "@" + c, c + ".tape"))
+        sets = lambda k: {c + "_set_A": Ah[:k], c + "_set_b": bh[:k], c + "_set_x": xh[:k]}  # noqa: E731
+        o.solve_batch(sets(64), c + "_getOutputs", 64, mu0=solve_args["mu0"], maxIter=solve_args["maxIter"])
+        t0 = time.perf_counter()
+        out, st, it = o.solve_batch(sets(n), c + "_getOutputs", n, mu0=solve_args["mu0"], maxIter=solve_args["maxIter"])
+        dt = time.perf_counter() - t0
+        what = "oracle/tc_oracle.c (tape interpreter + restated ipmPD_CSsolver loop, gcc -O1)"
     return {"value": float((st == 0).sum()) / dt, "unit": "solves/s", "cores": 1, "kind": "port",
-            "sample": "first %d instances of the benchmark batch, oracle/tc_oracle.c (tape interpreter + "
-                      "restated ipmPD_CSsolver loop, gcc -O1), sequential on 1 of %d host cores, %.1f s"
-                      % (n, os.cpu_count(), dt),
+            "sample": "first %d instances of the benchmark batch, %s, sequential on 1 of %d host cores, %.1f s"
+                      % (n, what, os.cpu_count(), dt),
             "us_per_solve": dt / n * 1e6}
 
 
