@@ -103,6 +103,10 @@ class Printer:
         L = self.L
         if vec[0] == "X":
             d = [x for x in L.inputs if x["dist"] and x["arr"] == vec[1]][0]
+            if not d.get("resident", True):
+                # too large to keep in registers: read this lane's element from the distributed
+                # block on every use (still one 512-byte line per wave-load)
+                return f"c.Sd[(long)({d['off'] + vec[2] * d['K'] + k}) * c.sdB]"
             return f"c.dX{vec[1]}[{vec[2] * d['K'] + k}]"
         return f"c.dF{vec[1]}[{k}]"
 
@@ -472,7 +476,7 @@ def _mask(groups):
 
 
 def emit_class(spec, fp_contract="fast", block=64, stats=False, roll=True, min_waves=0, lanes=1,
-               recip=False, fast_div=False, inline_max=0):
+               recip=False, fast_div=False, inline_max=0, reg_budget=150):
     """Return the HIP source text of the solver class.
 
     lanes=1: one thread per problem instance (generic lowering, bit-exact with fp_contract='off').
@@ -510,8 +514,14 @@ def emit_class(spec, fp_contract="fast", block=64, stats=False, roll=True, min_w
     w.append(f"#define TC_NM {max(1, L.nPriv)}\n#define TC_NEXT {L.nExt}\n#define TC_NOUT {nOut}\n"
              f"#define TC_NGROUPS {T.nGroups}\n#define TC_NSTW {nW}\n\n")
     dmembers = ""
+    # register budget for lane-distributed inputs (doubles per lane); larger inputs stay in HBM
+    budget = reg_budget
+    for d in sorted([x for x in L.inputs if x["dist"]], key=lambda x: x["rest"] * x["K"]):
+        d["resident"] = d["rest"] * d["K"] <= budget
+        if d["resident"]:
+            budget -= d["rest"] * d["K"]
     for d in L.inputs:
-        if d["dist"]:
+        if d["dist"] and d["resident"]:
             dmembers += f"  double dX{d['arr']}[{d['rest'] * d['K']}];\n"
     for f in L.dfamilies.values():
         dmembers += f"  double dF{f.fid}[{-(-f.n // L.P)}];\n"
@@ -525,7 +535,7 @@ def emit_class(spec, fp_contract="fast", block=64, stats=False, roll=True, min_w
              "typedef __attribute__((address_space(3))) double *tc_lds;\n"
              "typedef const __attribute__((address_space(1))) double *tc_glob;\n"
              f"typedef {mem_t} tc_mem;\n"
-             "struct TcCtx {\n  tc_mem m;\n  tc_glob S;\n  long B;\n  int lane;\n"
+             "struct TcCtx {\n  tc_mem m;\n  tc_glob S;\n  tc_glob Sd;\n  long B, sdB;\n  int lane;\n"
              "  unsigned long long st[TC_NSTW];\n" + dmembers +
              "#ifdef TC_STATS\n  int nMinF;\n  long long cyc[TC_NGROUPS];\n  int cnt[TC_NGROUPS];\n#endif\n};\n"
              f"#define SX(k) (S[(long)(k) * B])\n#define MM(k) {mm}\n"
@@ -654,8 +664,9 @@ def emit_class(spec, fp_contract="fast", block=64, stats=False, roll=True, min_w
                 "  for (int k = 0; k < TC_NSTW; k++) c.st[k] = 0;\n"
                 "#ifdef TC_STATS\n  c.nMinF = 0;\n  for (int k = 0; k < TC_NGROUPS; k++) { c.cyc[k] = 0; c.cnt[k] = 0; }\n"
                 "  const long long tstart_ = clock64();\n#endif\n")
+    prologue += "  c.Sd = (tc_glob)(Sd + tid * TC_P + c.lane);\n  c.sdB = B * TC_P;\n"
     for d in L.inputs:
-        if d["dist"]:
+        if d["dist"] and d["resident"]:
             cnt = d["rest"] * d["K"]
             prologue += (f"  _Pragma(\"unroll\") for (int j = 0; j < {cnt}; j++) "
                          f"c.dX{d['arr']}[j] = Sd[((long)({d['off']} + j) * B + tid) * TC_P + c.lane];\n")
@@ -785,7 +796,7 @@ def class_header(spec):
 
 def build_class(spec, fp_contract="fast", arch="gfx950", opt="-O3", block=64, force=False,
                 outdir=None, stats=False, tag=None, extra_flags=(), roll=True, min_waves=0, lanes=1,
-                recip=False, fast_div=False, inline_max=0):
+                recip=False, fast_div=False, inline_max=0, reg_budget=150):
     """Emit <cls>.hip (+ <cls>.h, <cls>.tape) and compile lib<cls>.so with hipcc for gfx950.
     Mirrors the createGateway/compile step of cmex2optimizeCS.m:403-417."""
     from .tapeio import save_tape
@@ -794,7 +805,8 @@ def build_class(spec, fp_contract="fast", arch="gfx950", opt="-O3", block=64, fo
     os.makedirs(outdir, exist_ok=True)
     suffix = f"_{tag}" if tag else ""
     src, L = emit_class(spec, fp_contract=fp_contract, block=block, stats=stats, roll=roll,
-                        min_waves=min_waves, lanes=lanes, recip=recip, fast_div=fast_div, inline_max=inline_max)
+                        min_waves=min_waves, lanes=lanes, recip=recip, fast_div=fast_div, inline_max=inline_max,
+                        reg_budget=reg_budget)
     hip = os.path.join(outdir, f"{cls}{suffix}.hip")
     so = os.path.join(outdir, f"lib{cls}{suffix}.so")
     flags = [opt, f"--offload-arch={arch}", "-fPIC", "-shared", "-std=c++17",

@@ -62,9 +62,10 @@ class DFamily:
 
 
 class Lowering:
-    def __init__(self, tape, code=None, roll=True, lanes=1):
+    def __init__(self, tape, code=None, roll=True, lanes=1, _replicate=()):
         T = self.T = tape
         self.P = int(lanes)
+        self._replicate = set(_replicate)    # inputs that must not be distributed (decided below)
         n = T.n
         opl, ost = T.ops.tolist(), T.opStart.tolist()
         self._opl, self._ost = opl, ost
@@ -83,7 +84,8 @@ class Lowering:
                 ins = e["ins"]
                 sz = e["size"]
                 n1 = sz[0] if len(sz) else 1
-                dist = P > 1 and len(sz) >= 1 and n1 >= 2 * P and len(ins) >= 4 * P
+                dist = (P > 1 and len(sz) >= 1 and n1 >= 2 * P and len(ins) >= 4 * P
+                        and e["varname"] not in self._replicate)
                 self.external[ins] = True
                 d = dict(name=e["varname"], entry=e["name"], size=sz, numel=len(ins), dist=dist)
                 if dist:
@@ -191,6 +193,40 @@ class Lowering:
                 k += 1
         self.pslot = pslot
         self.nPriv = k
+        # an input stays distributed only if every reader consumes it aligned (member c of a
+        # distributed family or term c of a reduction); otherwise redo the analysis with it replicated
+        if P > 1:
+            bad = set()
+            dm = {}
+            for fid, m in getattr(self, "_dcand", {}).items():
+                for c, i in enumerate(m):
+                    dm[i] = c
+            readers = {}
+            for i in range(1, n + 1):
+                if T.used[i] and grp[i] > 0:
+                    for j in set(self.operands(i)):
+                        readers.setdefault(j, []).append(i)
+            for d in self.inputs:
+                if not d["dist"]:
+                    continue
+                e = [x for x in T.sets if x["name"] == d["entry"]][0]
+                for q, i in enumerate(e["ins"]):
+                    i = int(i)
+                    row = q % d["n1"]
+                    if out_needed[i]:
+                        bad.add(d["name"])
+                        break
+                    for r_ in readers.get(i, []):
+                        top = self._consumer_root(r_, readers)
+                        if dm.get(top) == row or dm.get(r_) == row or r_ in self.dreduce:
+                            continue
+                        bad.add(d["name"])
+                        break
+                    if d["name"] in bad:
+                        break
+            if bad:
+                self.__init__(tape, code, roll, lanes, _replicate=self._replicate | bad)
+                return
         # ---- verify families against the final storage -----------------------------------------------------
         self._tree_cache = {}
         if P > 1:

@@ -249,3 +249,35 @@ def test_dcmotor_strict_bit_exact_vs_oracle(libs, tmp_path):
     assert np.array_equal(st, rst) and np.array_equal(it, rit) and (st == 0).all()
     got = np.concatenate([a.reshape(B, -1) for a in outs], axis=1)
     assert np.array_equal(got, ref)
+
+
+def test_odd_sized_sls_both_lowerings(libs, tmp_path):
+    """sls with N=37 rows (not a multiple of the 8 lanes: zero padding + masked tail terms in the
+    reductions) and n=5 unknowns: strict bit-exact, w8 within the stated tolerance."""
+    import __graft_entry__ as g
+    from tenscalc_amd.problems.sls import sls
+    from tenscalc_amd.tapeio import save_tape
+    from oracle.tc_oracle import Oracle
+    N, n, B = 37, 5, 777
+    spec = sls(N=N, n=n, classname="tmp_sls_37_5", folder=g.GENERATED)
+    tape = str(tmp_path / "s37.tape")
+    save_tape(spec.tape, tape)
+    rs = np.random.RandomState(5)
+    A = rs.random_sample((B, N, n))
+    b = rs.random_sample((B, N))
+    x0 = .02 * rs.random_sample((B, n))
+    At = np.ascontiguousarray(np.transpose(A, (0, 2, 1)))
+    c = spec.classname
+    ref, rst, rit = Oracle(tape).solve_batch({c + "_set_A": At.reshape(B, -1), c + "_set_b": b, c + "_set_x": x0},
+                                             c + "_getOutputs", B, mu0=1.0, maxIter=30)
+    for tag, exact in (("sls37_strict", True), ("sls37_w8", False)):
+        obj = _load(libs[tag], B)
+        obj.setP_A(At); obj.setP_b(b); obj.setV_x(x0)
+        st, it, _ = obj.solve(**SOLVE_ARGS)
+        J, x = obj.getOutputs()
+        got = np.concatenate([J.reshape(B, 1), x.reshape(B, n)], axis=1)
+        assert np.array_equal(st, rst)
+        if exact:
+            assert np.array_equal(it, rit) and np.array_equal(got, ref)
+        else:
+            assert np.abs(it - rit).max() <= 2 and np.abs(got - ref).max() <= 5e-5
