@@ -66,6 +66,10 @@ int tc_set(tc_solver_t *h, const char *name, const double *host, int64_t B);
 int tc_set_device(tc_solver_t *h, const char *name, const double *dev, int64_t B, int layout,
                   void *stream);
 
+/* warm start / receding horizon without leaving the device: input <- output of the previous solve
+ * (e.g. setV_x(obj,out.xWarm) of examples/mpcmhe/mpc_dcmotor.m:224-225); sizes must match */
+int tc_set_from_output(tc_solver_t *h, const char *inputName, const char *outputName, void *stream);
+
 /* ---- [status,iter,time]=solve(obj,mu0,maxIter,saveIter,addEye2Hessian): ipmPD_CSsolver(...)
  * scalars by pointer as in the reference; status/iter are [B] host arrays; *time = seconds
  * for the whole batch (kernel time).  saveIter is accepted and ignored (allowSave=0). */

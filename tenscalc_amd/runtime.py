@@ -65,6 +65,7 @@ def _bind(path):
     L.tc_destroy.argtypes = [c.c_void_p]
     L.tc_set.argtypes = [c.c_void_p, c.c_char_p, _dp, c.c_int64]
     L.tc_set_device.argtypes = [c.c_void_p, c.c_char_p, c.c_void_p, c.c_int64, c.c_int, c.c_void_p]
+    L.tc_set_from_output.argtypes = [c.c_void_p, c.c_char_p, c.c_char_p, c.c_void_p]
     L.tc_solve.argtypes = [c.c_void_p, _dp, _i32p, _i32p, _dp, _i32p, _i32p, _dp]
     L.tc_solve_async.argtypes = [c.c_void_p, c.c_double, c.c_int32, _dp, c.c_void_p]
     L.tc_get_outputs.argtypes = [c.c_void_p, c.POINTER(_dp), c.c_int64]
@@ -154,6 +155,11 @@ class HipSolver:
             raise ValueError(f"{name}: expected {self.B}x{inp['numel']} values")
         self._check(self._L.tc_set_device(self._h, name.encode(), ctypes.c_void_p(tensor.data_ptr()),
                                           self.B, int(layout), ctypes.c_void_p(stream or 0)))
+
+    def set_from_output(self, input_name, output_name, stream=None):
+        """input <- output of the previous solve, device to device (warm start, receding horizon)"""
+        self._check(self._L.tc_set_from_output(self._h, input_name.encode(), output_name.encode(),
+                                               ctypes.c_void_p(stream or 0)))
 
     def _input(self, name):
         for inp in self.inputs:

@@ -281,3 +281,35 @@ def test_odd_sized_sls_both_lowerings(libs, tmp_path):
             assert np.array_equal(it, rit) and np.array_equal(got, ref)
         else:
             assert np.abs(it - rit).max() <= 2 and np.abs(got - ref).max() <= 5e-5
+
+
+def test_receding_horizon_warm_start_on_device(libs):
+    """MPC loop of examples/mpcmhe/mpc_dcmotor.m:192-225 (setV_u(uWarm); setV_x(xWarm) from the previous
+    outputs): feeding the warm-start outputs back on the device equals the host round trip bit-for-bit."""
+    import __graft_entry__ as g
+    from tenscalc_amd.problems.mpc_dcmotor import SOLVE_ARGS as DC_ARGS, dcmotor_data, mpc_dcmotor
+    spec = mpc_dcmotor(folder=g.GENERATED)
+    B = 64
+    data = [dcmotor_data(2000 + k) for k in range(B)]
+    names = [n for n, _ in spec.parameters + spec.variables]
+    objs = [_load(libs["dcmotor_strict"], B) for _ in range(2)]
+    for obj in objs:
+        for n in names:
+            obj.set(n, np.stack([np.asarray(d[n], dtype=float).reshape(-1, order="F") for d in data]))
+    res = []
+    for step in range(3):
+        st = []
+        for which, obj in enumerate(objs):
+            s_, it, _ = obj.solve(**DC_ARGS)
+            out = obj.getOutputs(as_dict=True)
+            st.append((s_, it, out["J"], out["x"]))
+            if which == 0:      # device-side feedback
+                obj.set_from_output("x", "xWarm")
+                obj.set_from_output("u", "uWarm")
+            else:               # host round trip
+                obj.set("x", out["xWarm"])
+                obj.set("u", out["uWarm"])
+        assert all(np.array_equal(a, b) for a, b in zip(st[0], st[1])), step
+        assert (st[0][0] == 0).all()
+        res.append(st[0][2].copy())
+    assert not np.array_equal(res[0], res[1])          # the warm start did change the problem data
