@@ -148,7 +148,7 @@ def main():
                          "algorithmic_bytes_per_launch": ALGO_BYTES_PER_SOLVE * B,
                          "algorithmic_bytes_per_solve": ALGO_BYTES_PER_SOLVE},
         }
-        if not args.no_cpu and world >= 1:
+        if not args.no_cpu and world == 1:      # CPU baseline: rank 0 at N=1 only
             out["cpu_baseline"] = cpu_baseline(spec, A, b, x0, args.cpu_sample, SOLVE_ARGS)
         print(json.dumps(out), flush=True)
     if world > 1:

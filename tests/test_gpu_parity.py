@@ -313,3 +313,35 @@ def test_receding_horizon_warm_start_on_device(libs):
         assert (st[0][0] == 0).all()
         res.append(st[0][2].copy())
     assert not np.array_equal(res[0], res[1])          # the warm start did change the problem data
+
+
+@pytest.mark.parametrize("kind", ["eq", "eqonly", "free"])
+def test_template_branches_on_gpu(libs, tmp_path, kind):
+    """device Newton loop under the other #if combinations (nG>0 + useInertia + uncoupled alphas +
+    scaleCost; nF==0; unconstrained): strict bit-exact, w8 within tolerance."""
+    import __graft_entry__ as g
+    from tenscalc_amd.problems.small import small_ls
+    from tenscalc_amd.tapeio import save_tape
+    from oracle.tc_oracle import Oracle
+    spec = small_ls(kind, folder=g.GENERATED)
+    tape = str(tmp_path / "p.tape")
+    save_tape(spec.tape, tape)
+    B = 300
+    rs = np.random.RandomState(11)
+    A = rs.random_sample((B, 12, 4)); b = rs.random_sample((B, 12)); x0 = .02 * rs.random_sample((B, 4)) + .005
+    At = np.ascontiguousarray(np.transpose(A, (0, 2, 1)))
+    c = spec.classname
+    ref, rst, rit = Oracle(tape).solve_batch({c + "_set_A": At.reshape(B, -1), c + "_set_b": b, c + "_set_x": x0},
+                                             c + "_getOutputs", B, mu0=1e-2, maxIter=40)
+    for tag, exact in (("small_%s_strict" % kind, True), ("small_%s_w8" % kind, False)):
+        obj = _load(libs[tag], B)
+        obj.setP_A(At); obj.setP_b(b); obj.setV_x(x0)
+        st, it, _ = obj.solve(mu0=1e-2, maxIter=40)
+        J, x = obj.getOutputs()
+        got = np.concatenate([J.reshape(B, 1), x.reshape(B, 4)], axis=1)
+        if exact:
+            assert np.array_equal(st, rst) and np.array_equal(it, rit) and np.array_equal(got, ref, equal_nan=True)
+        else:
+            ok = (st == 0) & (rst == 0)
+            assert ok.mean() > 0.9 and (st[ok] == rst[ok]).all()
+            assert np.abs(got[ok] - ref[ok]).max() <= 1e-4
