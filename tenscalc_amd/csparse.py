@@ -768,16 +768,10 @@ class Tape:
             return ins  # already column-major sorted
 
         # entry points ---------------------------------------------------------------
-        T.sets, T.gets, T.copies = [], [], []
-        nE = 0
-        out_cols, in_cols = [], []       # (bit, instr array)
+        gets, copies, sets = [], [], []
         for g in cs.gets:
-            outs = [dict(name=nm, size=s.size, ins=full_ins(s, g["name"]))
-                    for nm, s in zip(g["output_names"], g["sources"])]
-            e = dict(name=g["name"], outputs=outs, bit=nE)
-            out_cols.append((nE, np.concatenate([o["ins"] for o in outs])))
-            nE += 1
-            T.gets.append(e)
+            gets.append(dict(name=g["name"], outputs=[dict(name=nm, size=s.size, ins=full_ins(s, g["name"]))
+                                                        for nm, s in zip(g["output_names"], g["sources"])]))
         for c in cs.copies:
             dst, src = [], []
             for d, s in zip(c["dests"], c["sources"]):
@@ -788,14 +782,48 @@ class Tape:
                                      "sparsity structures, you may need full() in the source")
                 dst.append(idd)
                 src.append(iss)
-            e = dict(name=c["name"], dst=np.concatenate(dst), src=np.concatenate(src), bit=nE)
+            copies.append(dict(name=c["name"], dst=np.concatenate(dst), src=np.concatenate(src)))
+        for s in cs.sets:
+            sets.append(dict(name=s["name"], varname=s["var"].par, size=s["var"].size,
+                             ins=full_ins(s["var"], s["name"]), external=s["external"]))
+        return Tape.from_instructions(types, opStart, ops, parStart, pars, sets, gets, copies, defines,
+                                      ldl_stats=list(cs.ldl_stats))
+
+    @staticmethod
+    def from_instructions(types, opStart, ops, parStart, pars, sets, gets, copies, defines, ldl_stats=()):
+        """Tape from a raw instruction table (CSR arrays, 1-based operand ids) and entry-point lists
+        sets=[{name,varname,size,ins,external}], gets=[{name,outputs:[{name,size,ins}]}],
+        copies=[{name,dst,src}]: computes dependency groups, their order, parents/children."""
+        T = Tape()
+        types = np.asarray(types, dtype=np.int32)
+        n = types.size
+        T.types, T.opStart, T.ops, T.parStart, T.pars = types, np.asarray(opStart), np.asarray(ops), \
+            np.asarray(parStart), np.asarray(pars, dtype=np.float64)
+        opStart, ops = T.opStart, T.ops
+        T.n = n
+        T.defines = dict(defines)
+        T.ldl_stats = list(ldl_stats)
+        T.sets, T.gets, T.copies = [], [], []
+        nE = 0
+        out_cols, in_cols = [], []       # (bit, instr array)
+        for g in gets:
+            e = dict(name=g["name"], outputs=[dict(o, ins=np.asarray(o["ins"], dtype=np.int64)) for o in g["outputs"]],
+                     bit=nE)
+            out_cols.append((nE, np.concatenate([o["ins"] for o in e["outputs"]])))
+            nE += 1
+            T.gets.append(e)
+        for c in copies:
+            e = dict(name=c["name"], dst=np.asarray(c["dst"], dtype=np.int64),
+                     src=np.asarray(c["src"], dtype=np.int64), bit=nE)
+            if e["dst"].shape != e["src"].shape:
+                raise ValueError(f"copy '{c['name']}': source/destination length mismatch")
             out_cols.append((nE, e["src"]))
             nE += 1
             T.copies.append(e)
         nOut = nE
-        for s in cs.sets:
-            e = dict(name=s["name"], varname=s["var"].par, size=s["var"].size,
-                     ins=full_ins(s["var"], s["name"]), external=s["external"], bit=nE)
+        for s_ in sets:
+            e = dict(name=s_["name"], varname=s_["varname"], size=tuple(s_["size"]),
+                     ins=np.asarray(s_["ins"], dtype=np.int64), external=bool(s_["external"]), bit=nE)
             in_cols.append((nE, e["ins"]))
             nE += 1
             T.sets.append(e)

@@ -34,3 +34,28 @@ def test_cli_builds_library(sls_tape_path, tmp_path):
     so = main([sls_tape_path, "--strict", "--out", str(tmp_path)])
     L = ctypes.CDLL(so, mode=ctypes.RTLD_LOCAL)
     assert hasattr(L, "tc_solve") and hasattr(L, "ipmPD_CSsolver") and hasattr(L, "tmp_minslsc2_set_A")
+
+
+def test_cg_files_roundtrip(sls_spec, tmp_path, tape_oracle):
+    """export to the documented .cg/.cgc/.cgio/.cgs container and back: same instructions, same
+    dependency groups, same solve."""
+    from tenscalc_amd.cgformat import load_cg, save_cg
+    from tenscalc_amd.problems.sls import sls_data
+    T = sls_spec.tape
+    base = str(tmp_path / "sls")
+    save_cg(T, base)
+    T2 = load_cg(base)
+    assert T2.n == T.n and np.array_equal(T2.types, T.types)
+    assert np.array_equal(T2.ops, T.ops) and np.array_equal(T2.pars, T.pars)
+    assert T2.nGroups == T.nGroups and np.array_equal(T2.group, T.group)
+    assert [e["name"] for e in T2.gets] == [e["name"] for e in T.gets]
+    assert [(e["name"], e["children"]) for e in T2.sets] == [(e["name"], e["children"]) for e in T.sets]
+    assert T2.defines["nF"] == 16 and T2.defines["gradTolerance"] == 1e-4
+    o1, o2 = tape_oracle(T, "a"), tape_oracle(T2, "b")
+    c = sls_spec.classname
+    A, b, x0 = sls_data(3)
+    r = []
+    for o in (o1, o2):
+        o.set(c + "_set_A", A); o.set(c + "_set_b", b); o.set(c + "_set_x", x0)
+        r.append((o.solve(1.0, 30), o.get(c + "_getOutputs")))
+    assert r[0][0] == r[1][0] and np.array_equal(r[0][1], r[1][1])
