@@ -53,11 +53,13 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
-    if world > 1:
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group(backend="nccl")   # RCCL on ROCm
+    if os.environ.get("TC_BENCH_SINGLE_DEVICE"):   # debugging aid: several ranks on one GPU (no RCCL over xGMI then)
+        local = 0
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group(backend="nccl", device_id=dev)   # RCCL on ROCm; one rank per GPU
 
     import __graft_entry__ as g
     from tenscalc_amd.problems.sls import SOLVE_ARGS, sls
@@ -70,9 +72,9 @@ def main():
             kw[k_] = int(v_)
         kw["tag"] = (kw.get("tag", "fast") + "_" + os.environ["TC_EXPERIMENT"].replace("=", "").replace(",", "_"))
     if rank == 0:
-        so = spec.build(**kw)
+        so = spec.build(**kw)          # prebuilt in-tree normally; compiles here only if missing
     if world > 1:
-        dist.barrier()
+        dist.barrier(device_ids=[local])
     so = spec.build(**kw)
 
     B = args.batch
@@ -103,7 +105,7 @@ def main():
     kern_ms = []
     evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
     if world > 1:
-        dist.barrier()
+        dist.barrier(device_ids=[local])
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for k in range(args.steps):
@@ -114,7 +116,8 @@ def main():
             gather_results(pack_results(O, ST, IT), world, out=gathered)
     torch.cuda.synchronize()
     if world > 1:
-        dist.barrier()
+        dist.barrier(device_ids=[local])
+        torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
     kern_ms = [a.elapsed_time(b_) for a, b_ in evs]          # events on the launch stream
     el = torch.tensor([elapsed], dtype=torch.float64, device=dev)
@@ -152,7 +155,7 @@ def main():
             out["cpu_baseline"] = cpu_baseline(spec, A, b, x0, args.cpu_sample, SOLVE_ARGS)
         print(json.dumps(out), flush=True)
     if world > 1:
-        dist.barrier()
+        dist.barrier(device_ids=[local])
         dist.destroy_process_group()
     obj.close()
 
