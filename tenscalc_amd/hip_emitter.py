@@ -422,33 +422,28 @@ class Printer:
                 for lf in self._den_leaves(L.tree(i), []):
                     cnt[lf.ins] = cnt.get(lf.ins, 0) + 1
             share = {j for j, c_ in cnt.items() if c_ >= 2}
-        for i in L.T.groups[g - 1]:
-            i = int(i)
-            if L.inline[i]:
+        from .lowering import DFamily
+        for u in L.units[g - 1]:
+            if isinstance(u, DFamily):
+                out.append(self.dfamily_body(u))
                 continue
-            if share and not L.in_family[i]:
+            if isinstance(u, Family):
+                e = self.expr(u.template, u)
+                dst = f"{u.dst0}+c_" if u.ddst == 1 else f"{u.dst0}+({u.ddst})*c_"
+                if L.P > 1:
+                    # the lanes sharing the instance split the members; LDS (in order within a
+                    # wave) makes every element visible to all of them afterwards
+                    out.append(f"  for (int c_ = lane; c_ < {u.n}; c_ += TC_P) {{ MM({dst}) = {e}; }}\n"
+                               "  __builtin_amdgcn_wave_barrier();\n")
+                else:
+                    out.append(f"  for (int c_ = 0; c_ < {u.n}; c_++) {{ MM({dst}) = {e}; }}\n")
+                continue
+            i = int(u)
+            if share:
                 for lf in self._den_leaves(L.tree(i), []):
                     if lf.ins in share and lf.ins not in self._rc:
                         self._rc[lf.ins] = f"rc{lf.ins}"
                         out.append(f"  const double rc{lf.ins} = TC_DIV(1.0,{self.leaf_text(lf)});\n")
-            dfam = L.dfamilies.get(i)
-            if dfam is not None:
-                out.append(self.dfamily_body(dfam))
-                continue
-            fam = L.families.get(i)
-            if fam is not None:
-                e = self.expr(fam.template, fam)
-                dst = f"{fam.dst0}+c_" if fam.ddst == 1 else f"{fam.dst0}+{fam.ddst}*c_"
-                if L.P > 1:
-                    # the lanes sharing the instance split the members; LDS (in order within a
-                    # wave) makes every element visible to all of them afterwards
-                    out.append(f"  for (int c_ = lane; c_ < {fam.n}; c_ += TC_P) {{ MM({dst}) = {e}; }}\n"
-                               "  __builtin_amdgcn_wave_barrier();\n")
-                else:
-                    out.append(f"  for (int c_ = 0; c_ < {fam.n}; c_++) {{ MM({dst}) = {e}; }}\n")
-                continue
-            if L.in_family[i]:
-                continue
             e = self.expr(L.tree(i))
             if L.local[i]:
                 out.append(f"  const double t{i} = {e};\n")

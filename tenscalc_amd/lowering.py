@@ -22,6 +22,7 @@ from . import instructions as I
 
 MAX_TERMS_PERLINE = 100   # instructionsTableUTHash.c:173
 V1_MIN = 6                # smallest element family rolled into a loop
+MINE_MIN = 4              # smallest mined family
 V2_MIN = 12               # smallest term family rolled into a loop
 
 
@@ -62,10 +63,16 @@ class DFamily:
 
 
 class Lowering:
-    def __init__(self, tape, code=None, roll=True, lanes=1, _replicate=()):
+    def __init__(self, tape, code=None, roll=True, lanes=1, _replicate=(), mine=None):
         T = self.T = tape
         self.P = int(lanes)
         self._replicate = set(_replicate)    # inputs that must not be distributed (decided below)
+        # "mined" families: same-shape, mutually independent instructions found by scanning each group
+        # (the reference's run detection, instructionsTableUTHash.c:881-944, without needing the
+        # members to be consecutive); on by default only when lanes share an instance, where a family
+        # is work split over the lanes -- with one thread per instance it would only move values
+        # from registers to memory
+        self.mine = (lanes > 1) if mine is None else bool(mine)
         n = T.n
         opl, ost = T.ops.tolist(), T.opStart.tolist()
         self._opl, self._ost = opl, ost
@@ -161,8 +168,9 @@ class Lowering:
         self.dreduce = {}           # sumprod/plus_sqr instruction id -> (nf, ns, factors)
         if P > 1:
             fam_members = self._classify_distributed(fam_members)
+        mined = self._mine_families(fam_members) if (roll and self.mine) else []
         # members (and their strided computed leaves) must live in indexable memory
-        for m in fam_members:
+        for m in fam_members + mined:
             for i in m:
                 if self.local[i]:
                     self.promote[i] = True
@@ -176,7 +184,7 @@ class Lowering:
         read_any |= out_needed
         pslot = np.full(n + 1, -1, dtype=np.int64)
         k = 0
-        for m in fam_members:
+        for m in fam_members + mined:
             for i in m:
                 if pslot[i] < 0 and not self.inline[i]:
                     pslot[i] = k
@@ -225,7 +233,7 @@ class Lowering:
                     if d["name"] in bad:
                         break
             if bad:
-                self.__init__(tape, code, roll, lanes, _replicate=self._replicate | bad)
+                self.__init__(tape, code, roll, lanes, _replicate=self._replicate | bad, mine=self.mine)
                 return
         # ---- verify families against the final storage -----------------------------------------------------
         self._tree_cache = {}
@@ -238,6 +246,26 @@ class Lowering:
             if f is not None:
                 self.families[min(m)] = f
                 self.in_family[m] = True
+        # mined candidates: keep the maximal affine sub-runs
+        self.mined_pieces = {}                # first member of a candidate -> [Family | instruction id, ...]
+        for m in mined:
+            pieces, k0 = [], 0
+            while k0 < len(m):
+                best = None
+                for k1 in range(k0 + MINE_MIN, len(m) + 1):
+                    f = self._family_verify(m[k0:k1])
+                    if f is None:
+                        break
+                    best = (k1, f)
+                if best is None:
+                    pieces.append(m[k0])
+                    k0 += 1
+                else:
+                    pieces.append(best[1])
+                    self.in_family[m[k0:best[0]]] = True
+                    k0 = best[0]
+            self.mined_pieces[m[0]] = pieces
+        self._build_units(mined)
 
     # -------------------------------------------------------------------------------------------
     def operands(self, i):
@@ -475,6 +503,116 @@ class Lowering:
                     leaves.append(("r", lf))
             self.dfamilies[min(m)] = DFamily(fid, m, t, leaves)
             self.in_family[m] = True
+
+    def _mine_families(self, fam_members):
+        """same-shape instructions at the same dependency level of a group = mutually independent
+        candidates, ordered by their operands so that storage indices have a chance to be affine"""
+        T = self.T
+        taken = set(self.dval)
+        for m in fam_members:
+            taken.update(m)
+        out = []
+        self._ilevel = np.zeros(T.n + 1, dtype=np.int64)
+        for g in range(1, T.nGroups + 1):
+            buckets = {}
+            for i in T.groups[g - 1]:
+                i = int(i)
+                lv = 0
+                for j in self._leaf_ids(i) if not self.inline[i] else self.operands(i):
+                    if T.group[j] == g:
+                        lv = max(lv, self._ilevel[j] + 1)
+                self._ilevel[i] = lv
+                if self.inline[i] or i in taken or not self.computed[i]:
+                    continue
+                buckets.setdefault((lv, self.shape_sig(i)), []).append(i)
+            for key in sorted(buckets, key=lambda k: (k[0], buckets[k][0])):
+                lst = buckets[key]
+                if len(lst) >= MINE_MIN:
+                    out.append(self._best_order(lst))
+        return out
+
+    def _best_order(self, lst):
+        """order the (independent) members so that as many as possible fall into runs whose operand
+        ids are arithmetic progressions: try each operand position as the primary sort key"""
+        leaves = {i: tuple(self._leaf_ids(i)) for i in lst}
+        nl = len(leaves[lst[0]])
+        best, best_score = None, -1
+        for p in range(max(1, nl)):
+            order = sorted(lst, key=lambda i: (leaves[i][p:p + 1], leaves[i]))
+            score, k0 = 0, 0
+            while k0 < len(order):
+                k1 = k0 + 1
+                if k1 < len(order):
+                    d = [b - a for a, b in zip(leaves[order[k0]], leaves[order[k1]])]
+                    while k1 < len(order) and [b - a for a, b in zip(leaves[order[k1 - 1]], leaves[order[k1]])] == d:
+                        k1 += 1
+                if k1 - k0 >= MINE_MIN:
+                    score += k1 - k0
+                k0 = k1
+            if score > best_score:
+                best, best_score = order, score
+        return best
+
+    def _build_units(self, mined):
+        """emission order of every group: units (family | distributed family | single instruction)
+        sorted topologically, ties by lowest instruction id"""
+        import heapq
+        T = self.T
+        unit_of = {}
+        units = {}
+        for key, f in self.families.items():
+            if any(f is p for pcs in self.mined_pieces.values() for p in pcs if not isinstance(p, int)):
+                continue
+            units[("f", key)] = (f, f.members)
+        for pcs in self.mined_pieces.values():
+            for p in pcs:
+                if not isinstance(p, int):
+                    units[("m", p.members[0])] = (p, p.members)
+        for key, f in self.dfamilies.items():
+            units[("d", key)] = (f, f.members)
+        for uk, (_, mem) in units.items():
+            for i in mem:
+                unit_of[i] = uk
+        self.units = []
+        for g in range(1, T.nGroups + 1):
+            glist = []
+            for i in T.groups[g - 1]:
+                i = int(i)
+                if self.inline[i]:
+                    continue
+                uk = unit_of.get(i)
+                if uk is None:
+                    uk = ("1", i)
+                    units[uk] = (i, [i])
+                    unit_of[i] = uk
+                if uk not in glist:
+                    glist.append(uk)
+            gset = set(glist)
+            deps = {uk: set() for uk in glist}
+            for uk in glist:
+                for i in units[uk][1]:
+                    for j in self._leaf_ids(i):
+                        vk = unit_of.get(j)
+                        if vk is not None and vk in gset and vk != uk:
+                            deps[uk].add(vk)
+            users = {uk: [] for uk in glist}
+            for uk, ds in deps.items():
+                for vk in ds:
+                    users[vk].append(uk)
+            ready = [(min(units[uk][1]), uk) for uk in glist if not deps[uk]]
+            heapq.heapify(ready)
+            order = []
+            left = {uk: len(ds) for uk, ds in deps.items()}
+            while ready:
+                _, uk = heapq.heappop(ready)
+                order.append(units[uk][0])
+                for wk in users[uk]:
+                    left[wk] -= 1
+                    if left[wk] == 0:
+                        heapq.heappush(ready, (min(units[wk][1]), wk))
+            if len(order) != len(glist):
+                raise AssertionError(f"group {g}: cyclic dependency between emission units")
+            self.units.append(order)
 
     def _leaf_ids(self, i):
         out = []
