@@ -168,6 +168,7 @@ class Lowering:
         self.dreduce = {}           # sumprod/plus_sqr instruction id -> (nf, ns, factors)
         if P > 1:
             fam_members = self._classify_distributed(fam_members)
+        fam_members = [self._best_order(m) for m in fam_members]
         mined = self._mine_families(fam_members) if (roll and self.mine) else []
         # members (and their strided computed leaves) must live in indexable memory
         for m in fam_members + mined:
@@ -239,29 +240,26 @@ class Lowering:
         self._tree_cache = {}
         if P > 1:
             self.build_dfamilies()
-        for m in fam_members:
-            if self.in_family[m].any():
-                continue
-            f = self._family_verify(m)
-            if f is not None:
-                self.families[min(m)] = f
-                self.in_family[m] = True
-        # mined candidates: keep the maximal affine sub-runs
+        # every candidate (tensor-node or mined): keep its maximal affine sub-runs
         self.mined_pieces = {}                # first member of a candidate -> [Family | instruction id, ...]
-        for m in mined:
+        for m in fam_members + mined:
             pieces, k0 = [], 0
             while k0 < len(m):
                 best = None
-                for k1 in range(k0 + MINE_MIN, len(m) + 1):
-                    f = self._family_verify(m[k0:k1])
-                    if f is None:
-                        break
-                    best = (k1, f)
+                if not self.in_family[m[k0]]:
+                    for k1 in range(k0 + MINE_MIN, len(m) + 1):
+                        if self.in_family[m[k0:k1]].any():
+                            break
+                        f = self._family_verify(m[k0:k1])
+                        if f is None:
+                            break
+                        best = (k1, f)
                 if best is None:
                     pieces.append(m[k0])
                     k0 += 1
                 else:
                     pieces.append(best[1])
+                    self.families[min(best[1].members)] = best[1]
                     self.in_family[m[k0:best[0]]] = True
                     k0 = best[0]
             self.mined_pieces[m[0]] = pieces
@@ -561,13 +559,7 @@ class Lowering:
         unit_of = {}
         units = {}
         for key, f in self.families.items():
-            if any(f is p for pcs in self.mined_pieces.values() for p in pcs if not isinstance(p, int)):
-                continue
             units[("f", key)] = (f, f.members)
-        for pcs in self.mined_pieces.values():
-            for p in pcs:
-                if not isinstance(p, int):
-                    units[("m", p.members[0])] = (p, p.members)
         for key, f in self.dfamilies.items():
             units[("d", key)] = (f, f.members)
         for uk, (_, mem) in units.items():
