@@ -636,11 +636,31 @@ def emit_class(spec, fp_contract="fast", block=64, stats=False, roll=True, min_w
         for g in e["parents"]:
             if g not in Dg:
                 w.append(f"  TC_NEED({g});\n")
+        pairs = []
         for d, s_ in zip(e["dst"], e["src"]):
             if L.external[d]:
                 raise NotImplementedError("copy into an external set")
             if L.pslot[d] >= 0:
-                w.append(f"  MM({L.pslot[d]}) = {P.ref(s_)};\n")
+                pairs.append((int(L.pslot[d]), L.leaf(s_)))
+        k0 = 0
+        while k0 < len(pairs):
+            # maximal run with affine destination and affine LDS / input source: split over the lanes
+            k1 = k0 + 1
+            if lanes > 1 and pairs[k0][1].kind in ("priv", "ext") and k1 < len(pairs):
+                dd = pairs[k1][0] - pairs[k0][0]
+                ds = pairs[k1][1].idx - pairs[k0][1].idx if pairs[k1][1].kind == pairs[k0][1].kind else None
+                while (k1 < len(pairs) and ds is not None and pairs[k1][1].kind == pairs[k0][1].kind
+                       and pairs[k1][0] == pairs[k0][0] + dd * (k1 - k0)
+                       and pairs[k1][1].idx == pairs[k0][1].idx + ds * (k1 - k0)):
+                    k1 += 1
+            if k1 - k0 >= 4:
+                src = ("MM" if pairs[k0][1].kind == "priv" else "SX") + f"({pairs[k0][1].idx}+({ds})*j_)"
+                w.append(f"  for (int j_ = lane; j_ < {k1 - k0}; j_ += TC_P) {{ MM({pairs[k0][0]}+({dd})*j_) = {src}; }}\n"
+                         "  __builtin_amdgcn_wave_barrier();\n")
+                k0 = k1
+            else:
+                w.append(f"  MM({pairs[k0][0]}) = {P.leaf_text(pairs[k0][1])};\n")
+                k0 += 1
         w.append(inval(e["children"]))
         w.append("}\n")
     # entry points the loop may reference under #if but that this problem does not have
