@@ -244,7 +244,9 @@ class Printer:
         red = {"add": "tc_allreduce", "min": "tc_allreduce_min", "max": "tc_allreduce_max"}[kind]
         body = f"({{ double a_ = {init};"
         for k0, k1, cols in runs:
-            body += f" for (int j_ = lane; j_ < {k1 - k0}; j_ += TC_P) {{ {step(cols)} }}"
+            for q in range(-(-(k1 - k0) // L.P)):
+                guard = "" if (q + 1) * L.P <= k1 - k0 else f"if (j_ < {k1 - k0}) "
+                body += f" {{ const int j_ = lane + {q * L.P}; {guard}{{ {step(cols)} }} }}"
         body += f" a_ = {red}(a_);"
         for k in singles:
             cols = []
@@ -433,7 +435,7 @@ class Printer:
                 if L.P > 1:
                     # the lanes sharing the instance split the members; LDS (in order within a
                     # wave) makes every element visible to all of them afterwards
-                    out.append(f"  for (int c_ = lane; c_ < {u.n}; c_ += TC_P) {{ MM({dst}) = {e}; }}\n"
+                    out.append(self.lane_loop("c_", u.n, f"MM({dst}) = {e};") +
                                "  __builtin_amdgcn_wave_barrier();\n")
                 else:
                     out.append(f"  for (int c_ = 0; c_ < {u.n}; c_++) {{ MM({dst}) = {e}; }}\n")
@@ -450,6 +452,16 @@ class Printer:
             else:
                 out.append(f"  MM({L.pslot[i]}) = {e};\n")
         return "".join(out)
+
+    def lane_loop(self, var, n, body):
+        """members var = lane, lane+P, ... < n, fully unrolled: whole blocks of P members need no
+        predicate, only a ragged tail does"""
+        P_ = self.L.P
+        out = ""
+        for k in range(-(-n // P_)):
+            guard = "" if (k + 1) * P_ <= n else f"if ({var} < {n}) "
+            out += f"  {{ const int {var} = lane + {k * P_}; {guard}{{ {body} }} }}\n"
+        return out
 
     def ref(self, i):
         return self.leaf_text(self.L.leaf(i))
@@ -655,7 +667,7 @@ def emit_class(spec, fp_contract="fast", block=64, stats=False, roll=True, min_w
                     k1 += 1
             if k1 - k0 >= 4:
                 src = ("MM" if pairs[k0][1].kind == "priv" else "SX") + f"({pairs[k0][1].idx}+({ds})*j_)"
-                w.append(f"  for (int j_ = lane; j_ < {k1 - k0}; j_ += TC_P) {{ MM({pairs[k0][0]}+({dd})*j_) = {src}; }}\n"
+                w.append(P.lane_loop("j_", k1 - k0, f"MM({pairs[k0][0]}+({dd})*j_) = {src};") +
                          "  __builtin_amdgcn_wave_barrier();\n")
                 k0 = k1
             else:
