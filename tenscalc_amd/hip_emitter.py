@@ -518,7 +518,9 @@ def emit_class(spec, fp_contract="fast", block=64, stats=False, roll=True, min_w
               "alphaMin", "alphaMax", "muFactorAggressive", "muFactorConservative"]:
         w.append(f"#define {k} {_lit(spec.defines[k])}\n")
     nOut = sum(int(np.prod(sz)) if len(sz) else 1 for _, sz in spec.outputs)
-    w.append(f"#define TC_NM {max(1, L.nPriv)}\n#define TC_NEXT {L.nExt}\n#define TC_NOUT {nOut}\n"
+    nmp = max(1, L.nPriv)
+    nmp += (8 - nmp) % 32
+    w.append(f"#define TC_NM {max(1, L.nPriv)}\n#define TC_NMP {nmp}\n#define TC_NEXT {L.nExt}\n#define TC_NOUT {nOut}\n"
              f"#define TC_NGROUPS {T.nGroups}\n#define TC_NSTW {nW}\n\n")
     dmembers = ""
     # register budget for lane-distributed inputs (doubles per lane); larger inputs stay in HBM
@@ -533,7 +535,10 @@ def emit_class(spec, fp_contract="fast", block=64, stats=False, roll=True, min_w
     for f in L.dfamilies.values():
         dmembers += f"  double dF{f.fid}[{-(-f.n // L.P)}];\n"
     mem_t = "tc_priv" if lanes == 1 else "tc_lds"
-    mm = "(m[k])" if lanes == 1 else "(m[(k) * TC_G])"
+    # LDS layout [instance-in-block][slot], slot count padded to 8 mod 32 doubles: the 8 lanes of an
+    # instance reading 8 consecutive slots and the 4 instances of a half-wave then hit 32 distinct
+    # 8-byte bank pairs (conflict-free ds_read_b64); a slot read by all lanes of an instance is a broadcast
+    mm = "(m[k])"
     w.append("// per-instance state: m = scratch for values crossing group boundaries (private memory when\n"
              "// one thread owns the instance, LDS [slot][instance] when TC_P lanes share it), S = this\n"
              "// instance's column of the structure-of-arrays input block (element k at S[k*B]), dX*/dF* =\n"
@@ -686,7 +691,7 @@ def emit_class(spec, fp_contract="fast", block=64, stats=False, roll=True, min_w
                 "  if (tid >= B) return;\n"
                 "  TcCtx c;\n"
                 "#if TC_P == 1\n  double mm_[TC_NM];\n  c.m = (tc_priv)mm_;\n"
-                "#else\n  __shared__ double tc_lds_m[TC_NM * TC_G];\n  c.m = (tc_lds)&tc_lds_m[threadIdx.x / TC_P];\n#endif\n"
+                "#else\n  __shared__ double tc_lds_m[TC_NMP * TC_G];\n  c.m = (tc_lds)&tc_lds_m[(threadIdx.x / TC_P) * TC_NMP];\n#endif\n"
                 "  c.lane = (int)(t_ % TC_P);\n  c.S = (tc_glob)(S + tid);\n  c.B = B;\n"
                 "  for (int k = 0; k < TC_NSTW; k++) c.st[k] = 0;\n"
                 "#ifdef TC_STATS\n  c.nMinF = 0;\n  for (int k = 0; k < TC_NGROUPS; k++) { c.cyc[k] = 0; c.cnt[k] = 0; }\n"
