@@ -116,10 +116,24 @@ class Printer:
         nf, ns, facs = L.dreduce[t.ins]
         P_ = L.P
         K = -(-ns // P_)
+        # a literal factor that is a power of two scales every term exactly: take it out of the sum
+        # (bit-identical result, one multiplication instead of one per term)
+        import math
+        scale = 1.0
+        skip = set()
+        for p, (kind, v) in enumerate(facs):
+            lf = t.kids[p]
+            if kind == "r" and lf.kind == "lit" and lf.val != 0 and math.frexp(abs(lf.val))[0] == 0.5:
+                scale *= lf.val
+                skip.add(p)
+        if len(skip) == len(facs):
+            skip, scale = set(), 1.0
         terms = []
         for k in range(K):
             fs = []
             for p, (kind, v) in enumerate(facs):
+                if p in skip:
+                    continue
                 if kind == "d":
                     fs.append(self.vec_ref(v, k))
                 else:
@@ -131,7 +145,7 @@ class Printer:
         e = terms[0]
         for tk in terms[1:]:
             e = f"({e})+{tk}"
-        return f"tc_allreduce({e})"
+        return f"tc_allreduce({e})" if scale == 1.0 else f"({_lit(scale)}*tc_allreduce({e}))"
 
     def dfamily_body(self, f):
         L = self.L
