@@ -12,8 +12,14 @@ from tenscalc_amd.problems.mpc_dcmotor import SOLVE_ARGS, dcmotor_data, mpc_dcmo
 from tenscalc_amd.runtime import HipSolver
 
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 4096
+variant = sys.argv[2] if len(sys.argv) > 2 else "strict"
 spec = mpc_dcmotor(folder=g.GENERATED)
-so = spec.build(**g.VARIANT_KW["strict"])
+if variant == "strict":
+    so = spec.build(**g.VARIANT_KW["strict"])
+else:                                    # e.g. w64: 64 lanes share one instance, state in LDS
+    kw = dict(g.VARIANT_KW["w8"])
+    kw.update(lanes=int(variant[1:]), tag=variant, inline_max=32)
+    so = spec.build(**kw)
 data = [dcmotor_data(k) for k in range(B)]
 names = [n for n, _ in spec.parameters + spec.variables]
 obj = HipSolver(so, B=B)
@@ -27,7 +33,7 @@ t = float(np.median(ts))
 nin = sum(int(np.prod(s)) if len(s) else 1 for _, s in spec.parameters + spec.variables)
 nout = sum(int(np.prod(s)) if len(s) else 1 for _, s in spec.outputs)
 algo = 8 * (nin + nout) + 8
-print(f"mpc_dcmotor strict B={B}: {t*1e3:.2f} ms/batch, {B/t:.3e} solves/s, status0 {np.mean(st==0):.4f}, "
+print(f"mpc_dcmotor {variant} B={B}: {t*1e3:.2f} ms/batch, {B/t:.3e} solves/s, status0 {np.mean(st==0):.4f}, "
       f"iter median {np.median(it)}, max {it.max()}; algorithmic {algo} B/solve -> {algo*B/t/1e9:.2f} GB/s")
 try:
     from oracle.c_emitter import CpuTwin
@@ -37,7 +43,10 @@ try:
     t0 = time.perf_counter()
     out, st2, it2 = tw.solve_batch(stacked, n, mu0=SOLVE_ARGS["mu0"], maxIter=SOLVE_ARGS["maxIter"])
     dt = time.perf_counter() - t0
+    outs = obj.getOutputs()
+    got = np.concatenate([a.reshape(B, -1) for a in outs], axis=1)[:n]
     print(f"cpu twin (1 core): {dt/n*1e6:.1f} us/solve = {n/dt:.3e} solves/s; identical status/iter: "
-          f"{np.array_equal(st[:n], st2) and np.array_equal(it[:n], it2)}")
+          f"{np.array_equal(st[:n], st2) and np.array_equal(it[:n], it2)}; max |output diff| {np.abs(got-out).max():.3e}, "
+          f"|J diff| {np.abs(got[:,0]-out[:,0]).max():.3e}")
 except (FileNotFoundError, OSError) as e:
     print("cpu twin unavailable", e)
