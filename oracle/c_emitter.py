@@ -16,7 +16,7 @@ import subprocess
 
 import numpy as np
 
-from tenscalc_amd.hip_emitter import Printer, _lit
+from tenscalc_amd.hip_emitter import Printer
 from tenscalc_amd.lowering import Lowering
 
 HERE = os.path.dirname(os.path.abspath(__file__))

@@ -1,7 +1,6 @@
 """ORACLE - test infrastructure only.  ctypes face of oracle/tc_oracle.c (+ the optional
 reference-loop build in oracle/_ref/)."""
 import ctypes
-import os
 
 import numpy as np
 

@@ -5,7 +5,6 @@ import os
 import sys
 
 sys.path.insert(0, os.getcwd())
-import numpy as np
 import torch
 
 import __graft_entry__ as g

@@ -1,8 +1,9 @@
-import sys, os, time
+"""Timing sweep over prebuilt sls class-library variants (by tag).  GPU box: python scripts/variant_sweep.py w8 strict"""
+import sys, os
 sys.path.insert(0, os.getcwd())
 import torch, numpy as np
 import __graft_entry__ as g
-from tenscalc_amd.problems.sls import SOLVE_ARGS, sls
+from tenscalc_amd.problems.sls import SOLVE_ARGS
 from tenscalc_amd.runtime import LAYOUT_BATCH_MINOR, HipSolver
 B=65536
 gen = torch.Generator(device='cuda').manual_seed(1234)

@@ -11,7 +11,7 @@ from __future__ import annotations
 
 from . import tcalculus as tc
 from .tcalculus import (Teye, Tones, Tvariable, Tzeros, cat, clp, compose, diag, full,
-                        gradient, hessian, ldl, ldl_d, ldl_l, mldivide, norminf, plus,
+                        gradient, hessian, ldl, ldl_d, ldl_l, mldivide, norminf,
                         rdivide, substitute, tabs, times, tmin, tprod, transpose, tsum)
 
 

@@ -221,10 +221,6 @@ def toT(x):
     return Tconstant(x)
 
 
-def _is_zero(x):
-    return x.op == "zeros" or _prod(x.size) == 0 and x.op != "variable"
-
-
 def const_value(x):
     """Dense numpy value of a purely numeric node, or None."""
     if x.op == "constant":
@@ -929,8 +925,6 @@ def substitute(f, var, expr):
         pairs = tuple((v.idx, toT(e)) for v, e in zip(var, expr))
     else:
         pairs = ((var.idx, toT(expr)),)
-    for _, e in pairs:
-        pass
     mp = {i: e for i, e in pairs}
     ctx = tuple((i, e.idx) for i, e in pairs)
     return _subst(toT(f), mp, ctx)
