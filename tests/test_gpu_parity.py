@@ -147,6 +147,8 @@ def test_fast_build_within_stated_tolerance(libs, sls_spec, sls_tape_path, varia
     J, x = J.reshape(B), x.reshape(B, 8)
     ref, rst, rit = _oracle_batch(sls_spec, sls_tape_path, A, b, x0)
     assert np.array_equal(st, rst) and (st == 0).all()
+    st_b, it_b, _ = obj.solve(**SOLVE_ARGS)                       # deterministic: no atomics, fixed reduction trees
+    assert np.array_equal(it, it_b) and np.array_equal(obj.getOutputs()[1].reshape(B, 8), x)
     assert np.abs(it - rit).max() <= 2
     assert np.abs(J - ref[:, 0]).max() <= 5e-5
     assert np.abs(x - ref[:, 1:]).max() <= 5e-5
