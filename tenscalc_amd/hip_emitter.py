@@ -396,28 +396,25 @@ class Printer:
             return "+".join(f"{x}*{x}" for x in r)
         if typ == I.I_plus_abs:
             return "+".join(f"fabs({x})" for x in r)
-        if typ in (I.I_min, I.I_max):
-            f = "tc_min" if typ == I.I_min else "tc_max"
-            e = r[0]
-            for x in r[1:]:
-                e = f"{f}({e},{x})"
-            return e
-        if typ in (I.I_min0, I.I_max0):
-            f = "tc_min" if typ == I.I_min0 else "tc_max"
-            e = "0.0"
-            for x in r:
-                e = f"{f}({e},{x})"
-            return e
-        if typ == I.I_max_abs:
-            e = f"fabs({r[0]})"
-            for x in r[1:]:
-                e = f"tc_max({e},fabs({x}))"
-            return e
-        if typ == I.I_clp:
-            e = "DBL_MAX"
-            for k in range(0, len(r), 2):
-                e = f"tc_clp({e},{r[k]},{r[k + 1]})"
-            return e
+        if typ in (I.I_min, I.I_max, I.I_min0, I.I_max0, I.I_max_abs, I.I_clp):
+            # acc = first (or 0 / DBL_MAX); then one conditional update per operand, in operand order
+            # (instructionsTableUTHash.c:1227-1331).  Long lists are printed as a statement sequence:
+            # nesting hundreds of calls overflows the compiler's recursive descent.
+            f = "tc_min" if typ in (I.I_min, I.I_min0) else "tc_max"
+            if typ in (I.I_min, I.I_max):
+                init, steps = r[0], [f"{f}(a_,{x})" for x in r[1:]]
+            elif typ in (I.I_min0, I.I_max0):
+                init, steps = "0.0", [f"{f}(a_,{x})" for x in r]
+            elif typ == I.I_max_abs:
+                init, steps = f"fabs({r[0]})", [f"tc_max(a_,fabs({x}))" for x in r[1:]]
+            else:
+                init, steps = "DBL_MAX", [f"tc_clp(a_,{r[k]},{r[k + 1]})" for k in range(0, len(r), 2)]
+            if len(steps) <= 12:
+                e = init
+                for st_ in steps:
+                    e = st_.replace("a_", e, 1)
+                return e
+            return "({ double a_ = " + init + "; " + " ".join(f"a_ = {st_};" for st_ in steps) + " a_; })"
         if typ in _UNARY:
             return _UNARY[typ].format(r[0] if r else "")
         raise NotImplementedError(f"HIP emitter: opcode {I.NAMES.get(typ, typ)} not supported")
@@ -497,7 +494,7 @@ def _mask(groups):
 
 
 def emit_class(spec, fp_contract="fast", block=64, stats=False, roll=True, min_waves=0, lanes=1,
-               recip=False, fast_div=False, inline_max=0, reg_budget=150):
+               recip=False, fast_div=False, inline_max=0, reg_budget=150, scratch="auto"):
     """Return the HIP source text of the solver class.
 
     lanes=1: one thread per problem instance (generic lowering, bit-exact with fp_contract='off').
@@ -548,11 +545,18 @@ def emit_class(spec, fp_contract="fast", block=64, stats=False, roll=True, min_w
             dmembers += f"  double dX{d['arr']}[{d['rest'] * d['K']}];\n"
     for f in L.dfamilies.values():
         dmembers += f"  double dF{f.fid}[{-(-f.n // L.P)}];\n"
-    mem_t = "tc_priv" if lanes == 1 else "tc_lds"
+    # where values that cross group boundaries live: per-thread private memory (lanes=1), LDS shared by
+    # the lanes of an instance (lanes>1), or -- for tapes whose live state is too large for either --
+    # a structure-of-arrays block in HBM, M[slot][B] (scratch="global", lanes=1 only)
+    if scratch == "auto":
+        scratch = "private" if lanes == 1 else "lds"
+    if scratch == "global" and lanes != 1:
+        raise ValueError("scratch='global' needs lanes=1")
+    mem_t = {"private": "tc_priv", "lds": "tc_lds", "global": "tc_gmem"}[scratch]
     # LDS layout [instance-in-block][slot], slot count padded to 8 mod 32 doubles: the 8 lanes of an
     # instance reading 8 consecutive slots and the 4 instances of a half-wave then hit 32 distinct
     # 8-byte bank pairs (conflict-free ds_read_b64); a slot read by all lanes of an instance is a broadcast
-    mm = "(m[k])"
+    mm = "(m[k])" if scratch != "global" else "(m[(long)(k) * B])"
     w.append("// per-instance state: m = scratch for values crossing group boundaries (private memory when\n"
              "// one thread owns the instance, LDS [slot][instance] when TC_P lanes share it), S = this\n"
              "// instance's column of the structure-of-arrays input block (element k at S[k*B]), dX*/dF* =\n"
@@ -560,7 +564,8 @@ def emit_class(spec, fp_contract="fast", block=64, stats=False, roll=True, min_w
              "typedef __attribute__((address_space(5))) double *tc_priv;\n"
              "typedef __attribute__((address_space(3))) double *tc_lds;\n"
              "typedef const __attribute__((address_space(1))) double *tc_glob;\n"
-             f"typedef {mem_t} tc_mem;\n"
+             "typedef __attribute__((address_space(1))) double *tc_gmem;\n"
+             f"typedef {mem_t} tc_mem;\n#define TC_SCRATCH_{scratch.upper()} 1\n"
              "struct TcCtx {\n  tc_mem m;\n  tc_glob S;\n  tc_glob Sd;\n  long B, sdB;\n  int lane;\n"
              "  unsigned long long st[TC_NSTW];\n" + dmembers +
              "#ifdef TC_STATS\n  int nMinF;\n  long long cyc[TC_NGROUPS];\n  int cnt[TC_NGROUPS];\n#endif\n};\n"
@@ -704,7 +709,8 @@ def emit_class(spec, fp_contract="fast", block=64, stats=False, roll=True, min_w
                 "  const long tid = t_ / TC_P;\n"
                 "  if (tid >= B) return;\n"
                 "  TcCtx c;\n"
-                "#if TC_P == 1\n  double mm_[TC_NM];\n  c.m = (tc_priv)mm_;\n"
+                "#if defined(TC_SCRATCH_GLOBAL)\n  c.m = (tc_gmem)(Mg + tid);\n"
+                "#elif TC_P == 1\n  double mm_[TC_NM];\n  c.m = (tc_priv)mm_;\n"
                 "#else\n  __shared__ double tc_lds_m[TC_NMP * TC_G];\n  c.m = (tc_lds)&tc_lds_m[(threadIdx.x / TC_P) * TC_NMP];\n#endif\n"
                 "  c.lane = (int)(t_ % TC_P);\n  c.S = (tc_glob)(S + tid);\n  c.B = B;\n"
                 "  for (int k = 0; k < TC_NSTW; k++) c.st[k] = 0;\n"
@@ -722,7 +728,7 @@ def emit_class(spec, fp_contract="fast", block=64, stats=False, roll=True, min_w
     w.append("extern \"C\" __global__ void TC_LAUNCH_BOUNDS\n"
              "tc_solve_kernel(const double *__restrict__ S, const double *__restrict__ Sd, double *__restrict__ O,\n"
              "                int *__restrict__ status, int *__restrict__ iter, double mu0, int maxIter, double ae0,\n"
-             "                double ae1, long B, double *__restrict__ dbg) {\n" + prologue +
+             "                double ae1, long B, double *__restrict__ dbg, double *__restrict__ Mg) {\n" + prologue +
              "  int st = 0, it = 0;\n"
              "  ipmPD_CSsolver(c, mu0, maxIter, ae0, ae1, &st, &it);\n")
     for k, o in enumerate(outs):
@@ -744,7 +750,7 @@ def emit_class(spec, fp_contract="fast", block=64, stats=False, roll=True, min_w
     # probe kernel: init sequence then one get
     w.append("extern \"C\" __global__ void __launch_bounds__(TC_BLOCK)\n"
              "tc_probe_kernel(const double *__restrict__ S, const double *__restrict__ Sd, double *__restrict__ out,\n"
-             "                int which, double mu0, double ae0, double ae1, long B) {\n" + prologue +
+             "                int which, double mu0, double ae0, double ae1, long B, double *__restrict__ Mg) {\n" + prologue +
              "#if setAddEye2Hessian != 0\n  setAddEye2HessianU__(c, &ae0);\n  setAddEye2HessianEq__(c, &ae1);\n#endif\n"
              "  initPrimal__(c);\n"
              "#if scaleCost != 0\n  scaleCost__(c);\n#endif\n"
@@ -842,7 +848,7 @@ def class_header(spec):
 
 def build_class(spec, fp_contract="fast", arch="gfx950", opt="-O3", block=64, force=False,
                 outdir=None, stats=False, tag=None, extra_flags=(), roll=True, min_waves=0, lanes=1,
-                recip=False, fast_div=False, inline_max=0, reg_budget=150):
+                recip=False, fast_div=False, inline_max=0, reg_budget=150, scratch="auto"):
     """Emit <cls>.hip (+ <cls>.h, <cls>.tape) and compile lib<cls>.so with hipcc for gfx950.
     Mirrors the createGateway/compile step of cmex2optimizeCS.m:403-417."""
     from .tapeio import save_tape
@@ -852,7 +858,7 @@ def build_class(spec, fp_contract="fast", arch="gfx950", opt="-O3", block=64, fo
     suffix = f"_{tag}" if tag else ""
     src, L = emit_class(spec, fp_contract=fp_contract, block=block, stats=stats, roll=roll,
                         min_waves=min_waves, lanes=lanes, recip=recip, fast_div=fast_div, inline_max=inline_max,
-                        reg_budget=reg_budget)
+                        reg_budget=reg_budget, scratch=scratch)
     hip = os.path.join(outdir, f"{cls}{suffix}.hip")
     so = os.path.join(outdir, f"lib{cls}{suffix}.so")
     flags = [opt, f"--offload-arch={arch}", "-fPIC", "-shared", "-std=c++17",
