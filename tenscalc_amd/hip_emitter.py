@@ -494,8 +494,13 @@ def _mask(groups):
 
 
 def emit_class(spec, fp_contract="fast", block=64, stats=False, roll=True, min_waves=0, lanes=1,
-               recip=False, fast_div=False, inline_max=0, reg_budget=150, scratch="auto"):
+               recip=False, fast_div=False, inline_max=0, reg_budget=150, scratch="auto", body="code"):
     """Return the HIP source text of the solver class.
+
+    body="code": dependency groups are printed as HIP statements (the lowering of lowering.py).
+    body="interp": the groups stay DATA -- a word stream walked in lock step by every lane of a
+    wavefront (csrc/tc_interp.hip.inc, interp_schedule.py); lanes=1, state in HBM.  For tapes too
+    large to print (tens of thousands of instructions).
 
     lanes=1: one thread per problem instance (generic lowering, bit-exact with fp_contract='off').
     lanes=P>1: P lanes cooperate on one instance -- large inputs and the element families built on
@@ -503,7 +508,14 @@ def emit_class(spec, fp_contract="fast", block=64, stats=False, roll=True, min_w
     once), long sums become per-lane partial sums + a DPP butterfly all-reduce, everything else is
     computed redundantly by the P lanes on per-instance state held in LDS."""
     T = spec.tape
-    L = Lowering(T, getattr(spec, "code", None), roll=roll, lanes=lanes)
+    interp = body == "interp"
+    if interp:
+        if lanes != 1:
+            raise ValueError("body='interp' needs lanes=1")
+        scratch = "global"
+        L = Lowering(T, None, roll=False, lanes=1, spill_all=True)
+    else:
+        L = Lowering(T, getattr(spec, "code", None), roll=roll, lanes=lanes)
     if block % lanes:
         raise ValueError("block must be a multiple of lanes")
     P = Printer(L, roll=roll, recip=recip)
@@ -529,9 +541,16 @@ def emit_class(spec, fp_contract="fast", block=64, stats=False, roll=True, min_w
               "alphaMin", "alphaMax", "muFactorAggressive", "muFactorConservative"]:
         w.append(f"#define {k} {_lit(spec.defines[k])}\n")
     nOut = sum(int(np.prod(sz)) if len(sz) else 1 for _, sz in spec.outputs)
+    consts, const_row = [], {}
+    if interp:
+        # constants read by instructions get rows of their own above the computed values
+        for i in range(1, T.n + 1):
+            if T.isload[i - 1] and T.used[i]:
+                const_row[i] = L.nPriv + len(consts)
+                consts.append(float(T.pars[T.parStart[i - 1]]))
     nmp = max(1, L.nPriv)
     nmp += (8 - nmp) % 32
-    w.append(f"#define TC_NM {max(1, L.nPriv)}\n#define TC_NMP {nmp}\n#define TC_NEXT {L.nExt}\n#define TC_NOUT {nOut}\n"
+    w.append(f"#define TC_NM {max(1, L.nPriv + len(consts))}\n#define TC_NMP {nmp}\n#define TC_NEXT {L.nExt}\n#define TC_NOUT {nOut}\n"
              f"#define TC_NGROUPS {T.nGroups}\n#define TC_NSTW {nW}\n\n")
     dmembers = ""
     # register budget for lane-distributed inputs (doubles per lane); larger inputs stay in HBM
@@ -556,7 +575,8 @@ def emit_class(spec, fp_contract="fast", block=64, stats=False, roll=True, min_w
     # LDS layout [instance-in-block][slot], slot count padded to 8 mod 32 doubles: the 8 lanes of an
     # instance reading 8 consecutive slots and the 4 instances of a half-wave then hit 32 distinct
     # 8-byte bank pairs (conflict-free ds_read_b64); a slot read by all lanes of an instance is a broadcast
-    mm = "(m[k])" if scratch != "global" else "(m[(long)(k) * B])"
+    # HBM-resident state: one tile per wavefront, tile[row][64 instances] (rows of a tile contiguous)
+    mm = "(m[k])" if scratch != "global" else "(m[(long)(k) * 64])"
     w.append("// per-instance state: m = scratch for values crossing group boundaries (private memory when\n"
              "// one thread owns the instance, LDS [slot][instance] when TC_P lanes share it), S = this\n"
              "// instance's column of the structure-of-arrays input block (element k at S[k*B]), dX*/dF* =\n"
@@ -586,7 +606,48 @@ def emit_class(spec, fp_contract="fast", block=64, stats=False, roll=True, min_w
              "  if (dx < 0) { const double t = -x / dx; if (a > t) a = t; }\n  return a;\n}\n"
              '#include "tc_wave.hip.inc"\n\n')
     # dependency groups ------------------------------------------------------------------
+    stream, copy_rng, out_rng = [], {}, None
+    if interp:
+        from . import interp_schedule as isch
+
+        def row_of(j):
+            lf = L.leaf(int(j))
+            if lf.kind == "lit":
+                return const_row[int(j)]
+            if lf.kind == "ext":
+                return int(lf.idx) - L.nExt       # inputs sit just below the scratch rows
+            if lf.kind == "priv":
+                return int(lf.idx)
+            raise AssertionError(lf.kind)
+        stream, granges, gstats = isch.build_stream(T, row_of)
+        for e in T.copies:
+            if any(L.external[d] for d in e["dst"]):
+                raise NotImplementedError("copy into an external set")
+            keep = [(row_of(d), row_of(s_)) for d, s_ in zip(e["dst"], e["src"]) if L.pslot[d] >= 0]
+            copy_rng[e["name"]] = isch.copy_stream(stream, [d for d, _ in keep], [s_ for _, s_ in keep])
+        go = T.entry(f"{cls}_getOutputs")[2]
+        # every row the device walk will touch must be inside the tile: checked here, on the host
+        isch.validate_stream(stream, granges + list(copy_rng.values()), -L.nExt, L.nPriv + len(consts))
+        out_rows = [row_of(i) for o in go["outputs"] for i in o["ins"]]
+        if out_rows and (min(out_rows) < -L.nExt or max(out_rows) >= L.nPriv + len(consts)):
+            raise AssertionError("output row outside the tile")
+        out_rng = isch.gather_table(stream, out_rows)
+        arr = isch.as_array(stream + [0] * 8)          # the header prefetch looks one record past the end
+        w.append(f"// the tape as data: {arr.size} words, {len(consts)} constants\n"
+                 "static __device__ const int tc_code[] __attribute__((aligned(64))) = {\n")
+        for k0 in range(0, arr.size, 32):
+            w.append(",".join(str(int(x)) for x in arr[k0:k0 + 32]) + ",\n")
+        w.append("};\nstatic __device__ const double tc_consts[] = {"
+                 + ", ".join(_lit(v) for v in consts) + ("" if consts else "0.0") + "};\n"
+                 f"#define TC_NCONST {len(consts)}\n#define TC_NPRIV {L.nPriv}\n"
+                 '#include "tc_interp.hip.inc"\n\n')
+        for g, members in enumerate(T.groups, 1):
+            w.append(f"// group {g}: {len(members)} instructions in {gstats[g - 1][1]} levels, "
+                     f"{int(T.flops[g].sum())} flops\n"
+                     f"#define TC_CALL_GRP{g} tc_interp(c.m, {granges[g - 1][0]}, {granges[g - 1][1]})\n")
     for g, members in enumerate(T.groups, 1):
+        if interp:
+            break
         w.append(f"// group {g}: {len(members)} instructions, {int(T.flops[g].sum())} flops\n")
         if P.group_uses_distributed(g) or len(members) <= inline_max:
             # small groups are inlined at their call sites: a call costs more than they do
@@ -673,6 +734,11 @@ def emit_class(spec, fp_contract="fast", block=64, stats=False, roll=True, min_w
             if g not in Dg:
                 w.append(f"  TC_NEED({g});\n")
         pairs = []
+        if interp:
+            w.append(f"  tc_interp(c.m, {copy_rng[e['name']][0]}, {copy_rng[e['name']][1]});\n")
+            w.append(inval(e["children"]))
+            w.append("}\n")
+            continue
         for d, s_ in zip(e["dst"], e["src"]):
             if L.external[d]:
                 raise NotImplementedError("copy into an external set")
@@ -709,7 +775,7 @@ def emit_class(spec, fp_contract="fast", block=64, stats=False, roll=True, min_w
                 "  const long tid = t_ / TC_P;\n"
                 "  if (tid >= B) return;\n"
                 "  TcCtx c;\n"
-                "#if defined(TC_SCRATCH_GLOBAL)\n  c.m = (tc_gmem)(Mg + tid);\n"
+                "#if defined(TC_SCRATCH_GLOBAL)\n  c.m = (tc_gmem)(Mg + ((tid >> 6) * (long)(TC_NEXT + TC_NM) + TC_NEXT) * 64 + (tid & 63));\n"
                 "#elif TC_P == 1\n  double mm_[TC_NM];\n  c.m = (tc_priv)mm_;\n"
                 "#else\n  __shared__ double tc_lds_m[TC_NMP * TC_G];\n  c.m = (tc_lds)&tc_lds_m[(threadIdx.x / TC_P) * TC_NMP];\n#endif\n"
                 "  c.lane = (int)(t_ % TC_P);\n  c.S = (tc_glob)(S + tid);\n  c.B = B;\n"
@@ -717,6 +783,9 @@ def emit_class(spec, fp_contract="fast", block=64, stats=False, roll=True, min_w
                 "#ifdef TC_STATS\n  c.nMinF = 0;\n  for (int k = 0; k < TC_NGROUPS; k++) { c.cyc[k] = 0; c.cnt[k] = 0; }\n"
                 "  const long long tstart_ = clock64();\n#endif\n")
     prologue += "  c.Sd = (tc_glob)(Sd + tid * TC_P + c.lane);\n  c.sdB = B * TC_P;\n"
+    if interp:
+        prologue += ("  for (int k = 0; k < TC_NCONST; k++) c.m[(long)(TC_NPRIV + k) * 64] = tc_consts[k];\n"
+                     "  for (int k = 0; k < TC_NEXT; k++) c.m[(long)(k - TC_NEXT) * 64] = S[(long)k * B + tid];\n")
     for d in L.inputs:
         if d["dist"] and d["resident"]:
             cnt = d["rest"] * d["K"]
@@ -731,17 +800,26 @@ def emit_class(spec, fp_contract="fast", block=64, stats=False, roll=True, min_w
              "                double ae1, long B, double *__restrict__ dbg, double *__restrict__ Mg) {\n" + prologue +
              "  int st = 0, it = 0;\n"
              "  ipmPD_CSsolver(c, mu0, maxIter, ae0, ae1, &st, &it);\n")
-    for k, o in enumerate(outs):
-        w.append(f"  double y{k + 1}[{max(1, len(o['ins']))}];\n")
-    w.append(f"  {cls}_getOutputs(c, " + ", ".join(f"y{k + 1}" for k in range(len(outs))) + ");\n")
-    w.append("  if (c.lane != 0) return;\n")
     off = 0
     out_meta = []
-    for k, o in enumerate(outs):
-        n_ = len(o["ins"])
-        w.append(f"  for (int j = 0; j < {n_}; j++) O[(long)({off} + j) * B + tid] = y{k + 1}[j];\n")
-        out_meta.append((o["name"], o["size"], n_, off))
-        off += n_
+    if interp:
+        w.append("  {\n")
+        for g in T.entry(f"{cls}_getOutputs")[2]["parents"]:
+            w.append(f"    TC_NEED({g});\n")
+        w.append(f"    tc_gather(c.m, c.B, {out_rng[0]}, {out_rng[1]}, O, tid);\n  }}\n")
+        for k, o in enumerate(outs):
+            out_meta.append((o["name"], o["size"], len(o["ins"]), off))
+            off += len(o["ins"])
+    else:
+        for k, o in enumerate(outs):
+            w.append(f"  double y{k + 1}[{max(1, len(o['ins']))}];\n")
+        w.append(f"  {cls}_getOutputs(c, " + ", ".join(f"y{k + 1}" for k in range(len(outs))) + ");\n")
+        w.append("  if (c.lane != 0) return;\n")
+        for k, o in enumerate(outs):
+            n_ = len(o["ins"])
+            w.append(f"  for (int j = 0; j < {n_}; j++) O[(long)({off} + j) * B + tid] = y{k + 1}[j];\n")
+            out_meta.append((o["name"], o["size"], n_, off))
+            off += n_
     w.append("  status[tid] = st;\n  iter[tid] = it;\n"
              "#ifdef TC_STATS\n  if (dbg) {\n    for (int k = 0; k < TC_NGROUPS; k++) {\n"
              "      dbg[(long)k * B + tid] = (double)c.cyc[k];\n      dbg[(long)(TC_NGROUPS + k) * B + tid] = (double)c.cnt[k];\n    }\n"
@@ -772,6 +850,14 @@ def emit_class(spec, fp_contract="fast", block=64, stats=False, roll=True, min_w
             po += n_
         w.append("    } break;\n")
     w.append("    default: break;\n  }\n}\n\n")
+    w.append(_class_tail(spec, T, L, out_meta, probes, lanes, nOut))
+    return "".join(w), L
+
+
+def _class_tail(spec, T, L, out_meta, probes, lanes, nOut):
+    """metadata tables + reference-name wrappers + the host runtime (shared by every back-end)"""
+    cls = spec.classname
+    w = []
     # metadata tables ---------------------------------------------------------------------------
     isvar = {nm for nm, _ in spec.variables}
 
@@ -827,7 +913,7 @@ def emit_class(spec, fp_contract="fast", block=64, stats=False, roll=True, min_w
            + ", ".join(f"y{k + 1}" for k in range(len(out_meta))) + "}; tc_compat_get(o_); }\n")
     w.append("#define TC_COMPAT_WRAPPERS \\\n" + cw)
     w.append('\n#include "tc_runtime.hip.inc"\n')
-    return "".join(w), L
+    return "".join(w)
 
 
 def class_header(spec):
@@ -848,7 +934,7 @@ def class_header(spec):
 
 def build_class(spec, fp_contract="fast", arch="gfx950", opt="-O3", block=64, force=False,
                 outdir=None, stats=False, tag=None, extra_flags=(), roll=True, min_waves=0, lanes=1,
-                recip=False, fast_div=False, inline_max=0, reg_budget=150, scratch="auto"):
+                recip=False, fast_div=False, inline_max=0, reg_budget=150, scratch="auto", body="code"):
     """Emit <cls>.hip (+ <cls>.h, <cls>.tape) and compile lib<cls>.so with hipcc for gfx950.
     Mirrors the createGateway/compile step of cmex2optimizeCS.m:403-417."""
     from .tapeio import save_tape
@@ -858,13 +944,13 @@ def build_class(spec, fp_contract="fast", arch="gfx950", opt="-O3", block=64, fo
     suffix = f"_{tag}" if tag else ""
     src, L = emit_class(spec, fp_contract=fp_contract, block=block, stats=stats, roll=roll,
                         min_waves=min_waves, lanes=lanes, recip=recip, fast_div=fast_div, inline_max=inline_max,
-                        reg_budget=reg_budget, scratch=scratch)
+                        reg_budget=reg_budget, scratch=scratch, body=body)
     hip = os.path.join(outdir, f"{cls}{suffix}.hip")
     so = os.path.join(outdir, f"lib{cls}{suffix}.so")
     flags = [opt, f"--offload-arch={arch}", "-fPIC", "-shared", "-std=c++17",
              f"-ffp-contract={fp_contract}", "-I", CSRC, "-I", INCLUDE, "-Wno-unused-value"] + list(extra_flags)
     deps = [os.path.join(CSRC, "ipm_newton.hip.inc"), os.path.join(CSRC, "tc_runtime.hip.inc"),
-            os.path.join(CSRC, "tc_wave.hip.inc"),
+            os.path.join(CSRC, "tc_wave.hip.inc"), os.path.join(CSRC, "tc_interp.hip.inc"),
             os.path.join(INCLUDE, "tenscalc_hip.h")]
     h = hashlib.sha256((src + " ".join(flags)).encode())
     for d in deps:

@@ -63,9 +63,12 @@ class DFamily:
 
 
 class Lowering:
-    def __init__(self, tape, code=None, roll=True, lanes=1, _replicate=(), mine=None):
+    def __init__(self, tape, code=None, roll=True, lanes=1, _replicate=(), mine=None, spill_all=False):
         T = self.T = tape
         self.P = int(lanes)
+        # spill_all: every computed value gets a memory slot (no inlining, no SSA temporaries): the
+        # storage map of the table-driven back-end (interp_emitter), where instructions are data
+        self.spill_all = bool(spill_all)
         self._replicate = set(_replicate)    # inputs that must not be distributed (decided below)
         # "mined" families: same-shape, mutually independent instructions found by scanning each group
         # (the reference's run detection, instructionsTableUTHash.c:881-944, without needing the
@@ -141,6 +144,9 @@ class Lowering:
         local = computed & ~read_other & ~out_needed
         # inline: local value with exactly one reader (one operand slot)
         inline = local & (nread == 1)
+        if spill_all:
+            local = np.zeros(n + 1, dtype=bool)
+            inline = np.zeros(n + 1, dtype=bool)
         self.computed = computed
         self.inline = inline
         self.local = local & ~inline                     # SSA temporaries
