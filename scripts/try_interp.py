@@ -31,6 +31,8 @@ def run(name, spec, data_fn, args, lib, Bs, Bcheck):
                   f"outputs bit-equal {np.array_equal(got, ref)} max|diff| {np.nanmax(np.abs(got-ref)):.3g}", flush=True)
         del obj
 
+import os
+VAR = os.environ.get("TC_VARIANT", "interp")
 which = sys.argv[1:] or ["sls", "dcmotor", "l1l2"]
 libs = {t: (b, kw) for t, b, kw in g.solver_variants()}
 if "sls" in which:
@@ -40,16 +42,16 @@ if "sls" in which:
     def d(s):
         r = rs(s); A = r.random_sample((100, 8)); b = r.random_sample(100); x = .02 * r.random_sample(8)
         return dict(A=A, b=b, x=x)
-    run("sls", spec, d, SOLVE_ARGS, spec.build(**libs["sls_interp"][1]), [64, 65536], 64)
+    run("sls", spec, d, SOLVE_ARGS, spec.build(**g.VARIANT_KW[VAR]), [64, 65536], 64)
 if "dcmotor" in which:
     from tenscalc_amd.problems.mpc_dcmotor import SOLVE_ARGS, dcmotor_data, mpc_dcmotor
     spec = mpc_dcmotor(folder=g.GENERATED)
-    run("dcmotor", spec, dcmotor_data, SOLVE_ARGS, spec.build(**libs["dcmotor_interp"][1]), [64, 4096, 32768], 64)
+    run("dcmotor", spec, dcmotor_data, SOLVE_ARGS, spec.build(**g.VARIANT_KW[VAR]), [64, 4096, 32768], 64)
 if "l1l2" in which:
     from tenscalc_amd.problems.l1l2 import SOLVE_ARGS, l1l2, l1l2_data
     spec = l1l2(folder=g.GENERATED)
-    run("l1l2", spec, l1l2_data, SOLVE_ARGS, spec.build(**libs["l1l2_interp"][1]), [8, 2048, 16384], 8)
+    run("l1l2", spec, l1l2_data, SOLVE_ARGS, spec.build(**g.VARIANT_KW[VAR]), [8, 2048, 16384], 8)
 if "quad" in which:
     from tenscalc_amd.problems.mpc_quadcopter import SOLVE_ARGS, mpc_quadcopter, quadcopter_data
     spec = mpc_quadcopter(folder=g.GENERATED)
-    run("quad", spec, quadcopter_data, SOLVE_ARGS, spec.build(**libs["quadcopter_interp"][1]), [4, 512], 4)
+    run("quad", spec, quadcopter_data, SOLVE_ARGS, spec.build(**g.VARIANT_KW[VAR]), [4, 512], 4)

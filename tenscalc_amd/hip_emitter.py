@@ -494,13 +494,15 @@ def _mask(groups):
 
 
 def emit_class(spec, fp_contract="fast", block=64, stats=False, roll=True, min_waves=0, lanes=1,
-               recip=False, fast_div=False, inline_max=0, reg_budget=150, scratch="auto", body="code"):
+               recip=False, fast_div=False, inline_max=0, reg_budget=150, scratch="auto", body="code",
+               waves=1):
     """Return the HIP source text of the solver class.
 
     body="code": dependency groups are printed as HIP statements (the lowering of lowering.py).
     body="interp": the groups stay DATA -- a word stream walked in lock step by every lane of a
     wavefront (csrc/tc_interp.hip.inc, interp_schedule.py); lanes=1, state in HBM.  For tapes too
-    large to print (tens of thousands of instructions).
+    large to print (tens of thousands of instructions).  waves=W: W wavefronts of one block share
+    the 64 instances of a tile and split the records of every level between them.
 
     lanes=1: one thread per problem instance (generic lowering, bit-exact with fp_contract='off').
     lanes=P>1: P lanes cooperate on one instance -- large inputs and the element families built on
@@ -513,6 +515,7 @@ def emit_class(spec, fp_contract="fast", block=64, stats=False, roll=True, min_w
         if lanes != 1:
             raise ValueError("body='interp' needs lanes=1")
         scratch = "global"
+        block = 64 * int(waves)
         L = Lowering(T, None, roll=False, lanes=1, spill_all=True)
     else:
         L = Lowering(T, getattr(spec, "code", None), roll=roll, lanes=lanes)
@@ -541,13 +544,10 @@ def emit_class(spec, fp_contract="fast", block=64, stats=False, roll=True, min_w
               "alphaMin", "alphaMax", "muFactorAggressive", "muFactorConservative"]:
         w.append(f"#define {k} {_lit(spec.defines[k])}\n")
     nOut = sum(int(np.prod(sz)) if len(sz) else 1 for _, sz in spec.outputs)
-    consts, const_row = [], {}
+    consts = []
     if interp:
-        # constants read by instructions get rows of their own above the computed values
-        for i in range(1, T.n + 1):
-            if T.isload[i - 1] and T.used[i]:
-                const_row[i] = L.nPriv + len(consts)
-                consts.append(float(T.pars[T.parStart[i - 1]]))
+        from . import interp_schedule as isch
+        consts = isch.constant_rows(T, L)[0]
     nmp = max(1, L.nPriv)
     nmp += (8 - nmp) % 32
     w.append(f"#define TC_NM {max(1, L.nPriv + len(consts))}\n#define TC_NMP {nmp}\n#define TC_NEXT {L.nExt}\n#define TC_NOUT {nOut}\n"
@@ -609,29 +609,9 @@ def emit_class(spec, fp_contract="fast", block=64, stats=False, roll=True, min_w
     stream, copy_rng, out_rng = [], {}, None
     if interp:
         from . import interp_schedule as isch
-
-        def row_of(j):
-            lf = L.leaf(int(j))
-            if lf.kind == "lit":
-                return const_row[int(j)]
-            if lf.kind == "ext":
-                return int(lf.idx) - L.nExt       # inputs sit just below the scratch rows
-            if lf.kind == "priv":
-                return int(lf.idx)
-            raise AssertionError(lf.kind)
-        stream, granges, gstats = isch.build_stream(T, row_of)
-        for e in T.copies:
-            if any(L.external[d] for d in e["dst"]):
-                raise NotImplementedError("copy into an external set")
-            keep = [(row_of(d), row_of(s_)) for d, s_ in zip(e["dst"], e["src"]) if L.pslot[d] >= 0]
-            copy_rng[e["name"]] = isch.copy_stream(stream, [d for d, _ in keep], [s_ for _, s_ in keep])
-        go = T.entry(f"{cls}_getOutputs")[2]
-        # every row the device walk will touch must be inside the tile: checked here, on the host
-        isch.validate_stream(stream, granges + list(copy_rng.values()), -L.nExt, L.nPriv + len(consts))
-        out_rows = [row_of(i) for o in go["outputs"] for i in o["ins"]]
-        if out_rows and (min(out_rows) < -L.nExt or max(out_rows) >= L.nPriv + len(consts)):
-            raise AssertionError("output row outside the tile")
-        out_rng = isch.gather_table(stream, out_rows)
+        cs = isch.class_stream(T, L, cls, int(waves))
+        stream, granges, gstats = cs["words"], cs["granges"], cs["gstats"]
+        copy_rng, out_rng, consts = cs["copy_rng"], cs["out_rng"], cs["consts"]
         arr = isch.as_array(stream + [0] * 8)          # the header prefetch looks one record past the end
         w.append(f"// the tape as data: {arr.size} words, {len(consts)} constants\n"
                  "static __device__ const int tc_code[] __attribute__((aligned(64))) = {\n")
@@ -639,12 +619,14 @@ def emit_class(spec, fp_contract="fast", block=64, stats=False, roll=True, min_w
             w.append(",".join(str(int(x)) for x in arr[k0:k0 + 32]) + ",\n")
         w.append("};\nstatic __device__ const double tc_consts[] = {"
                  + ", ".join(_lit(v) for v in consts) + ("" if consts else "0.0") + "};\n"
-                 f"#define TC_NCONST {len(consts)}\n#define TC_NPRIV {L.nPriv}\n"
+                 "static __device__ const int tc_rng[] __attribute__((aligned(64))) = {"
+                 + ", ".join(str(int(x)) for x in cs["table"]) + "};\n"
+                 f"#define TC_NCONST {len(consts)}\n#define TC_NPRIV {L.nPriv}\n#define TC_W {int(waves)}\n"
                  '#include "tc_interp.hip.inc"\n\n')
         for g, members in enumerate(T.groups, 1):
             w.append(f"// group {g}: {len(members)} instructions in {gstats[g - 1][1]} levels, "
                      f"{int(T.flops[g].sum())} flops\n"
-                     f"#define TC_CALL_GRP{g} tc_interp(c.m, {granges[g - 1][0]}, {granges[g - 1][1]})\n")
+                     f"#define TC_CALL_GRP{g} tc_interp(c.m, {cs['rid'][g]})\n")
     for g, members in enumerate(T.groups, 1):
         if interp:
             break
@@ -713,6 +695,8 @@ def emit_class(spec, fp_contract="fast", block=64, stats=False, roll=True, min_w
         if e["external"]:
             continue
         w.append(f"static __device__ __forceinline__ void {e['name']}(TcCtx &c, const double *input) {{\n  TC_UNPACK\n")
+        if interp and int(waves) > 1:
+            w.append("  tc_block_sync();\n")       # the other waves of the block may still be reading
         for k, i in enumerate(e["ins"]):
             if L.pslot[i] >= 0:
                 w.append(f"  MM({L.pslot[i]}) = input[{k}];\n")
@@ -735,7 +719,7 @@ def emit_class(spec, fp_contract="fast", block=64, stats=False, roll=True, min_w
                 w.append(f"  TC_NEED({g});\n")
         pairs = []
         if interp:
-            w.append(f"  tc_interp(c.m, {copy_rng[e['name']][0]}, {copy_rng[e['name']][1]});\n")
+            w.append(f"  tc_interp(c.m, {cs['rid'][e['name']]});\n")
             w.append(inval(e["children"]))
             w.append("}\n")
             continue
@@ -771,7 +755,9 @@ def emit_class(spec, fp_contract="fast", block=64, stats=False, roll=True, min_w
     # kernels -------------------------------------------------------------------------------
     outs = T.entry(f"{cls}_getOutputs")[2]["outputs"]
     # common kernel prologue: thread -> (instance, lane), per-instance state, distributed inputs
-    prologue = ("  const long t_ = (long)blockIdx.x * TC_BLOCK + threadIdx.x;\n"
+    prologue = ("#ifdef TC_W  // TC_W waves of the block share the 64 instances of tile blockIdx.x\n"
+                "  const long t_ = (long)blockIdx.x * 64 + (threadIdx.x & 63);\n#else\n"
+                "  const long t_ = (long)blockIdx.x * TC_BLOCK + threadIdx.x;\n#endif\n"
                 "  const long tid = t_ / TC_P;\n"
                 "  if (tid >= B) return;\n"
                 "  TcCtx c;\n"
@@ -806,7 +792,8 @@ def emit_class(spec, fp_contract="fast", block=64, stats=False, roll=True, min_w
         w.append("  {\n")
         for g in T.entry(f"{cls}_getOutputs")[2]["parents"]:
             w.append(f"    TC_NEED({g});\n")
-        w.append(f"    tc_gather(c.m, c.B, {out_rng[0]}, {out_rng[1]}, O, tid);\n  }}\n")
+        w.append("    if (threadIdx.x >= 64) return;   // the other waves of the block hold the same results\n"
+                 f"    tc_gather(c.m, c.B, {out_rng[0]}, {out_rng[1]}, O, tid);\n  }}\n")
         for k, o in enumerate(outs):
             out_meta.append((o["name"], o["size"], len(o["ins"]), off))
             off += len(o["ins"])
@@ -934,7 +921,8 @@ def class_header(spec):
 
 def build_class(spec, fp_contract="fast", arch="gfx950", opt="-O3", block=64, force=False,
                 outdir=None, stats=False, tag=None, extra_flags=(), roll=True, min_waves=0, lanes=1,
-                recip=False, fast_div=False, inline_max=0, reg_budget=150, scratch="auto", body="code"):
+                recip=False, fast_div=False, inline_max=0, reg_budget=150, scratch="auto", body="code",
+                waves=1):
     """Emit <cls>.hip (+ <cls>.h, <cls>.tape) and compile lib<cls>.so with hipcc for gfx950.
     Mirrors the createGateway/compile step of cmex2optimizeCS.m:403-417."""
     from .tapeio import save_tape
@@ -944,7 +932,7 @@ def build_class(spec, fp_contract="fast", arch="gfx950", opt="-O3", block=64, fo
     suffix = f"_{tag}" if tag else ""
     src, L = emit_class(spec, fp_contract=fp_contract, block=block, stats=stats, roll=roll,
                         min_waves=min_waves, lanes=lanes, recip=recip, fast_div=fast_div, inline_max=inline_max,
-                        reg_budget=reg_budget, scratch=scratch, body=body)
+                        reg_budget=reg_budget, scratch=scratch, body=body, waves=waves)
     hip = os.path.join(outdir, f"{cls}{suffix}.hip")
     so = os.path.join(outdir, f"lib{cls}{suffix}.so")
     flags = [opt, f"--offload-arch={arch}", "-fPIC", "-shared", "-std=c++17",

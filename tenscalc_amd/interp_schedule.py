@@ -5,7 +5,7 @@ The reference prints every scalar instruction as a C statement (writeCinstructio
 instructions the HIP back-end keeps them as data instead: per dependency group the instructions are
 level-scheduled (an instruction's level = 1 + the highest level among its operands inside the group),
 and same-shaped instructions of one level -- mutually independent by construction -- are packed into
-bundles of 8 / 2 / 1 so that one bundle has all of its operand loads in flight at once.  Instruction
+records of 16 / 8 / 1 so that one record has all of its operand loads in flight at once.  Instruction
 semantics are untouched: every instruction still evaluates its operands left to right exactly as the
 reference prints them, so results do not depend on the packing.
 """
@@ -17,6 +17,7 @@ from . import instructions as I
 
 NB = 6          # max operands of an instruction inside an 8-wide record (TC_NB)
 KB = 8          # record width
+KB2, NB2 = 16, 3  # wider records for instructions with few operands
 OP_COPY = 60    # pseudo-opcode: dest <- operand (copies / declareCopy entry points)
 _LONG_OPS = {I.I_sum, I.I_sumprod, I.I_plus_sqr, I.I_plus_abs, I.I_min, I.I_min0, I.I_max, I.I_max0,
              I.I_max_abs, I.I_clp, I.I_minus_dot, I.I_minus_dot_div, I.I_plus_minus_dot,
@@ -24,41 +25,75 @@ _LONG_OPS = {I.I_sum, I.I_sumprod, I.I_plus_sqr, I.I_plus_abs, I.I_min, I.I_min0
 _DOT_SKIP = {I.I_minus_dot: 0, I.I_minus_dot_div: 1, I.I_plus_minus_dot: 1, I.I_plus_minus_dot_div: 2}
 
 
-def _pad8(lst):
-    return list(lst) + [0] * (-len(lst) % 8)
+LONG_CHUNK = 32   # TC_CH: operands of a long instruction are fetched this many at a time
 
 
-def _emit(words, op, n, aux, items):
-    """items: list of (dest_row, [operand words row*2+neg]) with identical (op, n, aux).
-    Record layouts: csrc/tc_interp.hip.inc."""
+def _pad8(lst, m=8):
+    return list(lst) + [0] * (-len(lst) % m)
+
+
+OP_BARRIER = 2 << 8   # header word 0 of a barrier record (K code 2)
+
+
+def _records(op, n, aux, items, W=1):
+    """items: list of (dest_row, [operand words row*2+neg]) with identical (op, n, aux) and no
+    dependence on one another -> list of (cost, words) records.  Layouts: csrc/tc_interp.hip.inc."""
+    out = []
     if n > 8:
         if op not in _LONG_OPS:
             raise NotImplementedError(f"table-driven back-end: {n} operands for opcode {I.NAMES.get(op, op)}")
         skip = _DOT_SKIP.get(op, 0)
         for d, a in items:
             head = a[:skip] + [0, 0]
-            body = _pad8(a[skip:])
-            words += [op, n - skip, aux, d, head[0], head[1], 8 + len(body), 0] + body
-        return
+            body = _pad8(a[skip:], LONG_CHUNK)      # padded with row 0: loads need no guards
+            out.append((n + 24, [op, n - skip, aux, d, head[0], head[1], 8 + len(body), 0] + body))
+        return out
+    # wide records only while every wave of the block still gets a few of them
+    if n <= NB2 and len(items) >= 12 * W:
+        K = KB2
+    elif n <= NB and len(items) >= 3 * W:
+        K = KB
+    else:
+        K = 1
     k0 = 0
     while k0 < len(items):
         left = len(items) - k0
-        if n <= NB and left >= 3:
-            chunk = items[k0:k0 + KB]
-            chunk = chunk + [chunk[-1]] * (KB - len(chunk))   # pad: recomputes the last one
-            k0 += KB
-            words += [op | (KB << 8), n, aux, 0, 0, 0, 16 + 8 * n, 0]
-            words += [d for d, _ in chunk]
+        if K > 1 and left >= 3:
+            kk = K if left > KB or K == KB else KB
+            chunk = items[k0:k0 + kk]
+            chunk = chunk + [chunk[-1]] * (kk - len(chunk))   # pad: recomputes the last one
+            k0 += kk
+            w = [op | (kk << 8), n, aux, 0, 0, 0, 8 + kk + kk * n, 0]
+            w += [d for d, _ in chunk]
             for j in range(n):
-                words += [a[j] for _, a in chunk]
+                w += [a[j] for _, a in chunk]
+            out.append((kk * n + 24, w))
         else:
             d, a = items[k0]
             k0 += 1
-            words += [op | (1 << 8), n, aux, d, 0, 0, 16, 0] + _pad8(a)
+            out.append((n + 24, [op | (1 << 8), n, aux, d, 0, 0, 16, 0] + _pad8(a)))
+    return out
 
 
-def build_stream(T, row_of):
-    """Returns (words int32 array, group ranges [(start,end)] per group, level statistics).
+def _spread(level_records, W, streams):
+    """one level's records over the W waves of a block (longest first onto the least loaded wave),
+    then a barrier record in every wave's stream"""
+    if W == 1:
+        for _, w in level_records:
+            streams[0] += w
+        return
+    load = [0] * W
+    for cost, w in sorted(level_records, key=lambda r: -r[0]):
+        k = load.index(min(load))
+        load[k] += cost
+        streams[k] += w
+    for k in range(W):
+        streams[k] += [OP_BARRIER, 0, 0, 0, 0, 0, 8, 0]
+
+
+def build_stream(T, row_of, W=1):
+    """Returns (words, ranges, level statistics): ranges[g] = [(start, end)] * W, the record range
+    each of the W cooperating waves walks for dependency group g+1.
 
     row_of(j): state row (relative to the scratch base) holding the value of instruction j."""
     words = []
@@ -68,7 +103,6 @@ def build_stream(T, row_of):
     types = T.types
     grp = T.group
     for g, members in enumerate(T.groups, 1):
-        start = len(words)
         lvl = {}
         levels = {}
         for i in members.tolist():
@@ -78,6 +112,7 @@ def build_stream(T, row_of):
                     l_ = max(l_, lvl[j] + 1)
             lvl[i] = l_
             levels.setdefault(l_, []).append(i)
+        streams = [[] for _ in range(W)]
         for l_ in sorted(levels):
             shapes = {}
             for i in levels[l_]:
@@ -102,23 +137,36 @@ def build_stream(T, row_of):
                 if not a:               # I_2, I_zero: give the evaluator something to load
                     a = [d * 2]
                 shapes.setdefault((op, len(a), aux), []).append((d, a))
+            recs = []
             for (op, n, aux), items in sorted(shapes.items()):
-                _emit(words, op, n, aux, items)
-        ranges.append((start, len(words)))
+                recs += _records(op, n, aux, items, W)
+            _spread(recs, W, streams)
+        rg = []
+        for k in range(W):
+            rg.append((len(words), len(words) + len(streams[k])))
+            words += streams[k]
+        ranges.append(rg)
         stats.append((len(members), len(levels)))
     return words, ranges, stats
 
 
-def copy_stream(words, dst_rows, src_rows):
-    """dest <- source for a copy entry point; 8 at a time when no destination is also a source"""
-    start = len(words)
+def copy_stream(words, dst_rows, src_rows, W=1):
+    """dest <- source for a copy entry point -> [(start, end)] * W.  8 at a time spread over the
+    waves when no destination is also a source, else element by element on wave 0."""
     items = [(int(d), [int(s) * 2]) for d, s in zip(dst_rows, src_rows)]
+    streams = [[] for _ in range(W)]
     if set(int(d) for d in dst_rows) & set(int(s) for s in src_rows):
+        recs = []
         for d, a in items:              # keep the sequential element-by-element meaning
-            words += [OP_COPY | (1 << 8), 1, 0, d, 0, 0, 16, 0] + _pad8(a)
+            streams[0] += [OP_COPY | (1 << 8), 1, 0, d, 0, 0, 16, 0] + _pad8(a)
+        _spread([], W, streams)
     else:
-        _emit(words, OP_COPY, 1, 0, items)
-    return start, len(words)
+        _spread(_records(OP_COPY, 1, 0, items, W), W, streams)
+    rg = []
+    for k in range(W):
+        rg.append((len(words), len(words) + len(streams[k])))
+        words += streams[k]
+    return rg
 
 
 def gather_table(words, rows):
@@ -128,40 +176,108 @@ def gather_table(words, rows):
     return start, len(rows)
 
 
+def _record_rows(w, pc):
+    """(rows a lane touches, length) of the record at pc; raises on a malformed record"""
+    op, K = w[pc] & 255, w[pc] >> 8
+    n, ln = w[pc + 1], w[pc + 6]
+    if K in (KB, KB2):
+        if not (1 <= n <= (NB if K == KB else NB2)) or ln != 8 + K + K * n:
+            raise AssertionError(f"bad {K}-wide record at {pc}")
+        return w[pc + 8:pc + 8 + K] + [x >> 1 for x in w[pc + 8 + K:pc + 8 + K + K * n]], ln
+    if K == 1:
+        if not (1 <= n <= 8) or ln != 16:
+            raise AssertionError(f"bad single record at {pc}")
+        return [w[pc + 3]] + [x >> 1 for x in w[pc + 8:pc + 8 + n]], ln
+    if K == 0:
+        if n < 1 or ln != 8 + LONG_CHUNK * ((n + LONG_CHUNK - 1) // LONG_CHUNK) or op not in _LONG_OPS:
+            raise AssertionError(f"bad long record at {pc}")
+        if op in _DOT_SKIP and n % 2:
+            raise AssertionError(f"odd product operand count at {pc}")
+        skip = _DOT_SKIP.get(op, 0)
+        return ([w[pc + 3]] + [x >> 1 for x in w[pc + 8:pc + 8 + n]] + [x >> 1 for x in w[pc + 4:pc + 4 + skip]]), ln
+    raise AssertionError(f"bad record width {K} at {pc}")
+
+
 def validate_stream(words, ranges, lo, hi):
     """Walk every record range exactly as csrc/tc_interp.hip.inc does and check that each row a lane
-    would touch lies inside the tile (lo <= row < hi) and that the walk ends on the range end."""
+    would touch lies inside the tile (lo <= row < hi), that the walk ends on the range end, and that
+    the waves sharing a range meet the same number of barriers.  ranges: [[(start, end)] * W]."""
     w = words
-    for start, end in ranges:
-        if start % 8 or end % 8:
-            raise AssertionError("record range not 32-byte aligned")
-        pc = start
-        while pc < end:
-            op, K = w[pc] & 255, w[pc] >> 8
-            n, ln = w[pc + 1], w[pc + 6]
-            if K == 8:
-                if not (1 <= n <= NB) or ln != 16 + 8 * n:
-                    raise AssertionError(f"bad 8-wide record at {pc}")
-                rows = w[pc + 8:pc + 16] + [x >> 1 for x in w[pc + 16:pc + 16 + 8 * n]]
-            elif K == 1:
-                if not (1 <= n <= 8) or ln != 16:
-                    raise AssertionError(f"bad single record at {pc}")
-                rows = [w[pc + 3]] + [x >> 1 for x in w[pc + 8:pc + 8 + n]]
-            elif K == 0:
-                if n < 1 or ln != 8 + 8 * ((n + 7) // 8) or op not in _LONG_OPS:
-                    raise AssertionError(f"bad long record at {pc}")
-                rows = [w[pc + 3]] + [x >> 1 for x in w[pc + 8:pc + 8 + n]]
-                skip = _DOT_SKIP.get(op, 0)
-                rows += [x >> 1 for x in w[pc + 4:pc + 4 + skip]]
-                if op in _DOT_SKIP and n % 2:
-                    raise AssertionError(f"odd product operand count at {pc}")
-            else:
-                raise AssertionError(f"bad record width {K} at {pc}")
-            if min(rows) < lo or max(rows) >= hi:
-                raise AssertionError(f"row out of the tile in record at {pc}: {min(rows)}..{max(rows)} not in [{lo},{hi})")
-            pc += ln
-        if pc != end:
-            raise AssertionError("record walk does not end on the range end")
+    for rg in ranges:
+        nbar = set()
+        for start, end in rg:
+            if start % 8 or end % 8:
+                raise AssertionError("record range not 32-byte aligned")
+            pc, bars = start, 0
+            while pc < end:
+                if w[pc] == OP_BARRIER:
+                    if w[pc + 6] != 8:
+                        raise AssertionError(f"bad barrier record at {pc}")
+                    bars += 1
+                    pc += 8
+                    continue
+                rows, ln = _record_rows(w, pc)
+                if min(rows) < lo or max(rows) >= hi:
+                    raise AssertionError(f"row out of the tile in record at {pc}: {min(rows)}..{max(rows)} "
+                                         f"not in [{lo},{hi})")
+                pc += ln
+            if pc != end:
+                raise AssertionError("record walk does not end on the range end")
+            nbar.add(bars)
+        if len(nbar) > 1:
+            raise AssertionError("waves of one range do not meet the same number of barriers")
+
+
+def constant_rows(T, L):
+    """constants read by instructions get rows of their own above the computed values"""
+    consts, const_row = [], {}
+    for i in range(1, T.n + 1):
+        if T.isload[i - 1] and T.used[i]:
+            const_row[i] = L.nPriv + len(consts)
+            consts.append(float(T.pars[T.parStart[i - 1]]))
+    return consts, const_row
+
+
+def class_stream(T, L, classname, W=1):
+    """Everything the device walk needs for one class: group records, copy records, the output
+    gather table, and the row map (L = Lowering(T, spill_all=True))."""
+    consts, const_row = constant_rows(T, L)
+
+    def row_of(j):
+        lf = L.leaf(int(j))
+        if lf.kind == "lit":
+            return const_row[int(j)]
+        if lf.kind == "ext":
+            return int(lf.idx) - L.nExt       # inputs sit just below the scratch rows
+        if lf.kind == "priv":
+            return int(lf.idx)
+        raise AssertionError(lf.kind)
+    words, granges, gstats = build_stream(T, row_of, W)
+    copy_rng = {}
+    for e in T.copies:
+        if any(L.external[d] for d in e["dst"]):
+            raise NotImplementedError("copy into an external set")
+        keep = [(row_of(d), row_of(s_)) for d, s_ in zip(e["dst"], e["src"]) if L.pslot[d] >= 0]
+        copy_rng[e["name"]] = copy_stream(words, [d for d, _ in keep], [s_ for _, s_ in keep], W)
+    go = T.entry(f"{classname}_getOutputs")[2]
+    # every row the device walk will touch must be inside the tile: checked here, on the host
+    lo, hi = -L.nExt, L.nPriv + len(consts)
+    validate_stream(words, granges + list(copy_rng.values()), lo, hi)
+    out_rows = [row_of(i) for o in go["outputs"] for i in o["ins"]]
+    if out_rows and (min(out_rows) < lo or max(out_rows) >= hi):
+        raise AssertionError("output row outside the tile")
+    out_rng = gather_table(words, out_rows)
+    # range table the device indexes by (range id, wave): groups first, then the copies
+    rid = {}
+    table = []
+    for g, rg in enumerate(granges, 1):
+        rid[g] = len(table) // (2 * W)
+        table += [x for se in rg for x in se]
+    for name, rg in copy_rng.items():
+        rid[name] = len(table) // (2 * W)
+        table += [x for se in rg for x in se]
+    return dict(words=words, granges=granges, gstats=gstats, copy_rng=copy_rng, out_rng=out_rng,
+                consts=consts, const_row=const_row, row_of=row_of, lo=lo, hi=hi, W=W, rid=rid, table=table)
 
 
 def as_array(words):

@@ -1,0 +1,208 @@
+"""CPU: the record stream of the table-driven back-end (tenscalc_amd/interp_schedule.py), walked by a
+Python model of csrc/tc_interp.hip.inc, reproduces the oracle's value of EVERY instruction bit for bit.
+
+This pins the scheduler (levels, record packing, padding, row map, sign bits, long-instruction layout)
+without a GPU; the device walk itself is checked against the oracle in tests/test_gpu_interp.py."""
+import ctypes
+
+import numpy as np
+import pytest
+
+from tenscalc_amd import instructions as I
+from tenscalc_amd import interp_schedule as isch
+from tenscalc_amd.lowering import Lowering
+
+DOT_SKIP = {I.I_minus_dot: 0, I.I_minus_dot_div: 1, I.I_plus_minus_dot: 1, I.I_plus_minus_dot_div: 2}
+f64 = np.float64
+
+
+def _unary(op, x):
+    with np.errstate(all="ignore"):
+        return {
+            I.I_inv: lambda: f64(1) / x, I.I_minus_inv_sqr: lambda: f64(-1) / (x * x),
+            I.I_2_inv_cube: lambda: f64(2) / (x * x * x), I.I_abs: lambda: abs(x),
+            I.I_sign: lambda: f64(1 if x >= 0 else -1), I.I_sqrt: lambda: np.sqrt(x),
+            I.I_Dsqrt: lambda: f64(.5) * f64(float(x) ** -.5), I.I_DDsqrt: lambda: f64(-.25) * f64(float(x) ** -1.5),
+            I.I_sqr: lambda: x * x, I.I_2times: lambda: f64(2) * x, I.I_2: lambda: f64(2),
+            I.I_cube: lambda: x * x * x, I.I_3sqr: lambda: f64(3) * x * x, I.I_6times: lambda: f64(6) * x,
+            I.I_relu: lambda: x if x > 0 else f64(0), I.I_heaviside: lambda: f64(1 if x > 0 else 0),
+            isch.OP_COPY: lambda: x,
+        }[op]()
+
+
+def _eval(op, aux, v, sg):
+    """one instruction, operands v (signs sg for I_sum), in the reference's evaluation order"""
+    with np.errstate(all="ignore"):
+        if op == I.I_sum:
+            acc = -v[0] if sg[0] else v[0]
+            for x, s in zip(v[1:], sg[1:]):
+                acc = acc - x if s else acc + x
+            return acc
+        if op == I.I_sumprod:
+            total = line = None
+            nS = 0
+            ns = len(v) // aux
+            for s in range(ns):
+                x = v[s * aux]
+                for p in range(1, aux):
+                    x = x * v[s * aux + p]
+                line = x if line is None else line + x
+                if s + 1 < ns:
+                    nS += aux
+                    if nS >= 100:
+                        total = line if total is None else total + line
+                        line, nS = None, 0
+            return line if total is None else total + line
+        if op in DOT_SKIP:
+            sk = DOT_SKIP[op]
+            acc = v[sk] * v[sk + 1]
+            for k in range(sk + 2, len(v), 2):
+                acc = acc + v[k] * v[k + 1]
+            return {I.I_minus_dot: lambda: -acc, I.I_minus_dot_div: lambda: -acc / v[0],
+                    I.I_plus_minus_dot: lambda: v[0] - acc, I.I_plus_minus_dot_div: lambda: (v[0] - acc) / v[1]}[op]()
+        if op == I.I_div:
+            return v[0] / v[1]
+        if op in (I.I_plus_sqr, I.I_plus_abs):
+            f = (lambda x: x * x) if op == I.I_plus_sqr else abs
+            acc = f(v[0])
+            for x in v[1:]:
+                acc = acc + f(x)
+            return acc
+        if op in (I.I_min, I.I_max, I.I_min0, I.I_max0, I.I_max_abs):
+            xs = [abs(x) for x in v] if op == I.I_max_abs else list(v)
+            acc = f64(0) if op in (I.I_min0, I.I_max0) else xs.pop(0)
+            for x in xs:
+                if (acc > x) if op in (I.I_min, I.I_min0) else (acc < x):
+                    acc = x
+            return acc
+        if op == I.I_clp:
+            acc = f64(np.finfo(float).max)
+            for k in range(0, len(v), 2):
+                if v[k + 1] < 0:
+                    t = -v[k] / v[k + 1]
+                    if acc > t:
+                        acc = t
+            return acc
+        return _unary(op, v[0])
+
+
+def walk(words, ranges, m, base):
+    """Python model of tc_interp(): m[base + row] is the state of one instance; ranges = one
+    (start, end) per cooperating wave.  The waves run one at a time from barrier to barrier."""
+    pcs = [s_ for s_, _ in ranges]
+    while any(pc < e for pc, (_, e) in zip(pcs, ranges)):
+        for k, (_, e) in enumerate(ranges):
+            pcs[k] = _walk_to_barrier(words, pcs[k], e, m, base)
+    assert all(pc == e for pc, (_, e) in zip(pcs, ranges))
+
+
+def _walk_to_barrier(w, pc, end, m, base):
+    while pc < end:
+        op, K, n, aux, ln = w[pc] & 255, w[pc] >> 8, w[pc + 1], w[pc + 2], w[pc + 6]
+        if K == 2:
+            return pc + ln
+        if K >= 8:
+            dest = w[pc + 8:pc + 8 + K]
+            cols = [w[pc + 8 + K + K * j:pc + 8 + K + K * (j + 1)] for j in range(n)]
+            vals = [[m[base + (cols[j][k] >> 1)] for j in range(n)] for k in range(K)]      # all loads first
+            res = [_eval(op, aux, vals[k], [cols[j][k] & 1 for j in range(n)]) for k in range(K)]
+            for k in range(K):
+                m[base + dest[k]] = res[k]
+        elif K == 1:
+            a = w[pc + 8:pc + 8 + n]
+            m[base + w[pc + 3]] = _eval(op, aux, [m[base + (x >> 1)] for x in a], [x & 1 for x in a])
+        else:
+            sk = DOT_SKIP.get(op, 0)
+            a = list(w[pc + 4:pc + 4 + sk]) + list(w[pc + 8:pc + 8 + n])
+            m[base + w[pc + 3]] = _eval(op, aux, [m[base + (x >> 1)] for x in a], [x & 1 for x in a])
+        pc += ln
+    return pc
+
+
+def _check(spec, data, tape_oracle, args, W=1):
+    T = spec.tape
+    c = spec.classname
+    L = Lowering(T, None, roll=False, lanes=1, spill_all=True)
+    cs = isch.class_stream(T, L, c, W)
+    o = tape_oracle(T, c)
+    for nm, _ in spec.parameters + spec.variables:
+        o.set(f"{c}_set_{nm}", data[nm])
+    D = spec.defines
+    ae = args.get("addEye2Hessian", (1e-9, 1e-9))
+    if D["setAddEye2Hessian"]:
+        o.set("setAddEye2HessianU__", [ae[0]])
+        o.set("setAddEye2HessianEq__", [ae[1]])
+    o.copy("initPrimal__")
+    if D["scaleCost"]:
+        o.copy("scaleCost__")
+    if D["nF"] > 0:
+        if D["scaleInequalities"]:
+            o.copy("scaleIneq__")
+        o.set("setMu__", [args["mu0"]])
+        o.copy("initDualIneq__")
+    if D["nG"] > 0:
+        o.copy("initDualEqX__")
+    for e in T.gets:                       # evaluates every group a get depends on
+        o.get(e["name"])
+    val = lambda i: o.L.tco_value(o.h, ctypes.c_int64(int(i)))
+    base = -cs["lo"]
+    m = np.full(cs["hi"] - cs["lo"], np.nan)
+    for i in range(1, T.n + 1):            # inputs, internal sets, constants
+        if T.isset[i - 1] and (L.external[i] or L.pslot[i] >= 0):
+            m[base + cs["row_of"](i)] = val(i)
+    for i, r in cs["const_row"].items():
+        m[base + r] = cs["consts"][r - L.nPriv]
+    needed = sorted({g for e in T.gets for g in e["parents"]})
+    for g in needed:
+        walk(cs["words"], cs["granges"][g - 1], m, base)
+    bad = 0
+    for g in needed:
+        for i in T.groups[g - 1]:
+            a, b = m[base + cs["row_of"](i)], val(i)
+            if not (a == b or (a != a and b != b)):
+                bad += 1
+    assert bad == 0, f"{bad} instruction values differ from the oracle"
+    return cs
+
+
+def test_stream_sls(sls_spec, tape_oracle):
+    from tenscalc_amd.problems.sls import SOLVE_ARGS, sls_data
+    A, b, x0 = sls_data(3)
+    cs = _check(sls_spec, dict(A=A, b=b, x=x0), tape_oracle, SOLVE_ARGS)
+    kinds = {cs["words"][pc] >> 8 for pc in _headers(cs)}
+    assert {0, 1, 8, 16} <= kinds           # long, single, 8-wide and 16-wide records all occur
+
+
+def _headers(cs):
+    for rg in cs["granges"]:
+        for s, e in rg:
+            pc = s
+            while pc < e:
+                yield pc
+                pc += cs["words"][pc + 6]
+
+
+@pytest.mark.parametrize("W", [1, 4])
+def test_stream_dcmotor(native_built, tape_oracle, tmp_path, W):
+    """W=4: the records of every level spread over 4 cooperating waves, barrier records in between"""
+    from tenscalc_amd.problems.mpc_dcmotor import SOLVE_ARGS, dcmotor_data, mpc_dcmotor
+    spec = mpc_dcmotor(folder=str(tmp_path))
+    _check(spec, dcmotor_data(7), tape_oracle, SOLVE_ARGS, W)
+
+
+def test_stream_small_quadcopter(native_built, tape_oracle, tmp_path):
+    """sqrt / Dsqrt / DDsqrt / inv-family opcodes and long dot products (T=8 horizon)"""
+    from tenscalc_amd.problems.mpc_quadcopter import SOLVE_ARGS, mpc_quadcopter, quadcopter_data
+    spec = mpc_quadcopter(T=8, classname="tmp_quadcopter8", folder=str(tmp_path))
+    _check(spec, quadcopter_data(1, T=8), tape_oracle, SOLVE_ARGS, W=8)
+
+
+def test_validator_rejects_out_of_tile_rows(sls_spec):
+    T = sls_spec.tape
+    L = Lowering(T, None, roll=False, lanes=1, spill_all=True)
+    cs = isch.class_stream(T, L, sls_spec.classname)
+    w = list(cs["words"])
+    pc = cs["granges"][0][0][0]
+    w[pc + 8] = cs["hi"] * 2 + 100          # first operand/dest word of the first record
+    with pytest.raises(AssertionError):
+        isch.validate_stream(w, cs["granges"], cs["lo"], cs["hi"])
