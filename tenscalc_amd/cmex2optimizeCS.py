@@ -97,8 +97,12 @@ def cmex2optimizeCS(*, classname, objective, optimizationVariables, constraints=
                     delta=3, alphaMin=1e-7, alphaMax=1.0, coupledAlphas=True,
                     addEye2Hessian=True, adjustAddEye2Hessian=True, useInertia=False,
                     addEye2HessianUtolerance=1e-6, smallerNewtonMatrix=False, useLDL=True,
-                    useUmfpack=False, allowSave=False, solverVerboseLevel=0, **ignored):
+                    useUmfpack=False, allowSave=False, solverVerboseLevel=0, hoist=False, **ignored):
     """Generate an interior-point solver for ``min objective s.t. constraints``.
+
+    ``hoist=True`` (not a reference option) applies tenscalc_amd/hoist.py: products of
+    parameter-only factors in the derivatives are contracted first, so they are evaluated once
+    per solve instead of once per Newton iteration.  Same mathematics, different rounding.
 
     Unsupported reference options raise, exactly as ipmPD_CStimesLambda.m:31-48 does."""
     if not skipAffine:
@@ -149,9 +153,13 @@ def cmex2optimizeCS(*, classname, objective, optimizationVariables, constraints=
         outputExpressions = list(outputExpressions)
     else:
         lam = Tzeros((0,))
+    rewrite = None
+    if hoist:
+        from .hoist import Hoister
+        rewrite = Hoister(parameters).rewrite
     Tout = ipmPD_CStimesLambda(code, u, objective_u, F, G, lam, nu,
                                addEye2Hessian=addEye2Hessian, scaleCost=scaleCost,
-                               scaleInequalities=scaleInequalities, classname=classname)
+                               scaleInequalities=scaleInequalities, classname=classname, rewrite=rewrite)
     # outputs may refer to internal quantities through '<field>_' variables (cmex2optimizeCS.m:265-271)
     for fn, val in Tout.items():
         ph = Tvariable(fn + "_", val.size)

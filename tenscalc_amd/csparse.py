@@ -82,12 +82,26 @@ def _groups(sorted_keys):
     return brk.astype(np.int64), cnt.astype(np.int64)
 
 
-def min_degree_order(n, rows, cols, stages=None):
+LDL_GATE = "one"     # how `stages` constrains the elimination order (see min_degree_order)
+
+
+def min_degree_order(n, rows, cols, stages=None, gate=None):
     """Greedy minimum-degree elimination order of the symmetric pattern (rows,cols).
     Stands in for MATLAB ``symamd(A,[1000,0])`` at sparsity_ldl.m:91; any valid order
     gives the same solution up to rounding (SURVEY.md 7 hard part 1).  Ties are broken
-    by lowest index so the order is deterministic.  With ``stages`` every node of stage s
-    is eliminated before any node of stage s+1."""
+    by lowest index so the order is deterministic.
+
+    ``stages`` marks late nodes (stage>0: the equality duals of a KKT matrix, whose own diagonal
+    is only -addEye2HessianEq); ``gate`` says what a late node waits for:
+      "stage" every node of stage s is eliminated before any node of stage s+1 (numerically the
+              most conservative, but the Schur complement on the duals fills in: 2.1 M
+              multiply-adds per factorisation for mpc_quadcopter);
+      "all"   a late node becomes eligible once all its original stage-0 neighbours are gone;
+      "one"   ... once at least one of them is gone, i.e. as soon as its pivot has received a
+              Schur-complement contribution and is no longer the bare -1e-9 (55 k multiply-adds
+              for mpc_quadcopter, fill like the unconstrained order).
+    Default: module attribute LDL_GATE."""
+    gate = gate or LDL_GATE
     adj = [set() for _ in range(n)]
     for r, c in zip(rows, cols):
         r, c = int(r), int(c)
@@ -96,7 +110,24 @@ def min_degree_order(n, rows, cols, stages=None):
             adj[c].add(r)
     import heapq
     stg = [0] * n if stages is None else [int(s) for s in stages]
-    heap = [(stg[i], len(adj[i]), i) for i in range(n)]
+    if gate == "stage":
+        key = stg
+        need = [0] * n
+        gated_by = [()] * n
+    elif gate in ("all", "one"):
+        key = [0] * n
+        need = [0] * n
+        gated_by = [[] for _ in range(n)]
+        for i in range(n):
+            if stg[i]:
+                early = [a for a in adj[i] if stg[a] == 0]
+                need[i] = len(early) if gate == "all" else min(1, len(early))
+                for a in early:
+                    gated_by[a].append(i)
+    else:
+        raise ValueError("min_degree_order: gate must be 'stage', 'all' or 'one'")
+    seen = [0] * n                      # eliminated stage-0 neighbours of a late node
+    heap = [(key[i], len(adj[i]), i) for i in range(n) if need[i] == 0]
     heapq.heapify(heap)
     done = [False] * n
     order = []
@@ -115,8 +146,15 @@ def min_degree_order(n, rows, cols, stages=None):
             new.discard(a)
             if new:
                 adj[a] |= new
-            heapq.heappush(heap, (stg[a], len(adj[a]), a))
+            if seen[a] >= need[a]:
+                heapq.heappush(heap, (key[a], len(adj[a]), a))
+        for a in gated_by[i]:
+            seen[a] += 1
+            if not done[a] and seen[a] == need[a]:
+                heapq.heappush(heap, (key[a], len(adj[a]), a))
         adj[i] = set()
+    if len(order) != n:
+        raise AssertionError("min_degree_order: gated nodes left over")
     return np.array(order, dtype=np.int64)
 
 

@@ -16,10 +16,13 @@ from .tcalculus import (Teye, Tones, Tvariable, Tzeros, cat, clp, compose, diag,
 
 
 def ipmPD_CStimesLambda(code, u, f, F, G, lam, nu, *, addEye2Hessian=True, scaleCost=0.0,
-                        scaleInequalities=True, classname="cls"):
+                        scaleInequalities=True, classname="cls", rewrite=None):
     """Register every tape entry point of the IPM on ``code``; returns the named
-    expressions (``u, F, G, nu, lambda, Lf_u, Lf_uu, Hess, dHess, lHess, b, dx, mu``)."""
+    expressions (``u, F, G, nu, lambda, Lf_u, Lf_uu, Hess, dHess, lHess, b, dx, mu``).
+    ``rewrite``: optional expression rewriter applied to the derivatives before they are used
+    (tenscalc_amd/hoist.py; not part of the reference)."""
     out = {}
+    rw = rewrite if rewrite is not None else (lambda e: e)
     nU = u.size[0]
     nG = G.size[0] if G.ndim else 0
     nF = F.size[0] if F.ndim else 0
@@ -51,10 +54,10 @@ def ipmPD_CStimesLambda(code, u, f, F, G, lam, nu, *, addEye2Hessian=True, scale
     code.declareGet(f, "getJ__")
 
     # -- Lagrangian and derivatives (:124-187) ---------------------------------------------------
-    f_u = gradient(f, u)
+    f_u = rw(gradient(f, u))
     Lf = f
     if nF > 0:
-        F_u = gradient(F, u)
+        F_u = rw(gradient(F, u))
         gap = tprod(lam, (-1,), F, (-1,))
         Lf = Lf - gap
     else:
@@ -62,12 +65,13 @@ def ipmPD_CStimesLambda(code, u, f, F, G, lam, nu, *, addEye2Hessian=True, scale
         F_u = Tzeros((0, nU))
         gap = Tzeros(())
     if nG > 0:
-        G_u = gradient(G, u)
+        G_u = rw(gradient(G, u))
         Lf = Lf + tprod(nu, (-1,), G, (-1,))
     else:
         G = Tzeros((0,))
         G_u = Tzeros((0, nU))
     Lf_uu, Lf_u = hessian(Lf, u)
+    Lf_uu, Lf_u = rw(Lf_uu), rw(Lf_u)
     out["Lf_u"], out["Lf_uu"] = Lf_u, Lf_uu
     code.declareGet(Lf_u, "getGrad__")
     code.declareGet(norminf(Lf_u), "getNorminf_Grad__")

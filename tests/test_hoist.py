@@ -1,0 +1,65 @@
+"""Opt-in rewrite of tenscalc_amd/hoist.py: parameter-only factors are contracted first.  The
+rewritten expressions must evaluate to the same numbers (to rounding) as the originals through
+the same scalarizer + CPU oracle, and must lower the per-iteration work."""
+import numpy as np
+
+import tenscalc_amd.tcalculus as tc
+from tenscalc_amd.hoist import Hoister
+from test_csparse_ops import run
+
+EPS = np.finfo(float).eps
+
+
+def test_least_squares_gradient_is_hoisted(tape_oracle):
+    rs = np.random.RandomState(3)
+    A = tc.Tvariable("A", (11, 4)); b = tc.Tvariable("b", (11,)); x = tc.Tvariable("x", (4,))
+    J = tc.norm2(A * x - b) / 11
+    H, g = tc.hessian(J, x)
+    h = Hoister([A, b])
+    g2, H2 = h.rewrite(g), h.rewrite(H)
+    assert h.fast_cost(g2) * 4 < h.fast_cost(g)          # 2 passes over A -> one 4x4 product
+    assert H2 is H                                       # already parameter-only
+    assert [k for k, *_ in h.log] == ["reassociate", "distribute"] or len(h.log) >= 2
+    # the x-dependent part of the rewritten gradient no longer touches A or b directly
+    def direct_fast_users(f, seen):
+        if f.idx in seen or h.is_slow(f):
+            return set()
+        seen.add(f.idx)
+        u = {a.par for a in f.args if a.op == "variable" and a.idx in h.slow_vars}
+        for a in f.args:
+            u |= direct_fast_users(a, seen)
+        return u
+    assert direct_fast_users(g2, set()) == set()
+    assert direct_fast_users(g, set()) == {"A", "b"}
+    a, bv, xv = rs.rand(11, 4), rs.rand(11), rs.rand(4)
+    got, _, _ = run(tape_oracle, [A, b, x], [a, bv, xv], {"g": g, "g2": g2, "H": H})
+    want = 2 * a.T @ (a @ xv - bv) / 11
+    np.testing.assert_allclose(got["g"], want, rtol=1e3 * EPS, atol=1e3 * EPS)
+    np.testing.assert_allclose(got["g2"], want, rtol=1e3 * EPS, atol=1e3 * EPS)
+
+
+def test_rewrite_leaves_constant_structure_alone(tape_oracle):
+    """box constraints: F_u is built from eye/ones constants, no parameter -> nothing to hoist"""
+    x = tc.Tvariable("x", (5,)); lam = tc.Tvariable("lam", (10,))
+    F = tc.cat(1, x, 0.05 - x)
+    Fu = tc.gradient(F, x)
+    e = tc.transpose(Fu) * lam
+    h = Hoister([])
+    assert h.rewrite(e) is e and not h.log
+
+
+def test_general_chain_and_mixed_sum(tape_oracle):
+    """tprod(P, plus(fast, slow)) with a 3-factor inner product and a shared summation index"""
+    rs = np.random.RandomState(4)
+    P = tc.Tvariable("P", (6, 5)); Q = tc.Tvariable("Q", (5, 3)); c = tc.Tvariable("c", (5,))
+    x = tc.Tvariable("x", (3,)); w = tc.Tvariable("w", (6,))
+    inner = tc.tprod(Q, (1, -1), x, (-1,)) + c                 # Q x + c          (5)
+    e = tc.tprod(P, (-1, 1), w, (-1,), inner, (-2,), Q, (-2, 2))   # (P'w)_i * sum_k inner_k Q_kj   (6x5)(5x3) -> [5,3]
+    h = Hoister([P, Q, c])
+    e2 = h.rewrite(e)
+    p, q, cv, xv, wv = rs.rand(6, 5), rs.rand(5, 3), rs.rand(5), rs.rand(3), rs.rand(6)
+    got, _, _ = run(tape_oracle, [P, Q, c, x, w], [p, q, cv, xv, wv], {"e": e, "e2": e2})
+    want = np.outer(p.T @ wv, (q @ xv + cv) @ q)
+    np.testing.assert_allclose(got["e"], want, rtol=1e3 * EPS, atol=1e3 * EPS)
+    np.testing.assert_allclose(got["e2"], want, rtol=1e3 * EPS, atol=1e3 * EPS)
+    assert h.fast_cost(e2) <= h.fast_cost(e)
