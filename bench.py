@@ -39,9 +39,10 @@ def main():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--batch", type=int, default=65536, help="instances per GPU")
-    ap.add_argument("--variant", default=os.environ.get("TC_BENCH_VARIANT", "w8"), choices=["strict", "fast", "w8"],
+    ap.add_argument("--variant", default=os.environ.get("TC_BENCH_VARIANT", "w8"), choices=["strict", "fast", "w8", "w8h", "regs"],
                     help="strict: 1 thread/instance, -ffp-contract=off, bit-exact vs the oracle; fast: same with FMA; "
-                         "w8: 8 lanes/instance wave-cooperative lowering (default)")
+                         "w8: 8 lanes/instance wave-cooperative lowering (default); w8h / regs: the hoisted tape "
+                         "(parameter-only contractions first) under w8 / the register-resident lowering")
     ap.add_argument("--cpu-sample", type=int, default=int(os.environ.get("TC_CPU_SAMPLE", "65536")))
     ap.add_argument("--no-cpu", action="store_true")
     args = ap.parse_args()
@@ -64,7 +65,7 @@ def main():
     import __graft_entry__ as g
     from tenscalc_amd.problems.sls import SOLVE_ARGS, sls
     from tenscalc_amd.runtime import LAYOUT_BATCH_MINOR, HipSolver
-    spec = sls(folder=g.GENERATED)
+    spec = g.sls_spec(args.variant)
     kw = dict(g.VARIANT_KW[args.variant])
     if os.environ.get("TC_EXPERIMENT"):          # e.g. TC_EXPERIMENT="min_waves=2,block=256" (tuning runs)
         for kv in os.environ["TC_EXPERIMENT"].split(","):
@@ -152,7 +153,8 @@ def main():
                          "algorithmic_bytes_per_solve": ALGO_BYTES_PER_SOLVE},
         }
         if not args.no_cpu and world == 1:      # CPU baseline: rank 0 at N=1 only
-            out["cpu_baseline"] = cpu_baseline(spec, A, b, x0, args.cpu_sample, SOLVE_ARGS)
+            # always the reference's own tape (never the hoisted one): that is the path the reference runs
+            out["cpu_baseline"] = cpu_baseline(g.sls_spec("strict"), A, b, x0, args.cpu_sample, SOLVE_ARGS)
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.barrier(device_ids=[local])

@@ -60,5 +60,32 @@ def build_ref(tag, defines, opt="-O1"):
     return out
 
 
+DEFINE_NAMES = ["nU", "nG", "nF", "gradTolerance", "addEye2HessianUtolerance", "equalTolerance",
+                "desiredDualityGap", "scaleCost", "scaleInequalities", "scaleEqualities", "alphaMin",
+                "alphaMax", "coupledAlphas", "setAddEye2Hessian", "adjustAddEye2Hessian", "useInertia",
+                "muFactorAggressive", "muFactorConservative", "delta", "skipAffine",
+                "smallerNewtonMatrix", "useLDL", "useUmfpack", "allowSave"]
+
+
+def build_devloop(tag, defines, opt="-O1"):
+    """Host build (g++) of the device Newton loop tenscalc_amd/csrc/ipm_newton.hip.inc over the
+    oracle's tape interpreter (oracle/devloop_glue.cpp), one library per #define block."""
+    out = os.path.join(HERE, "_ref", "libdevloop_%s.so" % tag)
+    os.makedirs(os.path.join(HERE, "_ref"), exist_ok=True)
+    csrc = os.path.join(os.path.dirname(HERE), "tenscalc_amd", "csrc")
+    obj = out[:-3] + ".o"
+    defs = out[:-3] + "_defs.h"
+    with open(defs, "w") as f:
+        f.write("".join("#define %s %s\n" % (k, _fmt(defines[k])) for k in DEFINE_NAMES))
+    _run(["g++", "-w", opt, "-ffp-contract=off", "-fPIC", "-c", "-I", HERE, "-I", csrc,
+          '-DTC_DEFINES_H="%s"' % defs, os.path.join(HERE, "devloop_glue.cpp"), "-o", obj])
+    _run(["gcc", opt, "-ffp-contract=off", "-std=gnu99", "-fPIC", "-c", "-I", HERE,
+          os.path.join(HERE, "tc_oracle.c"), "-o", obj[:-2] + "_o.o"])
+    _run(["g++", "-shared", obj, obj[:-2] + "_o.o", "-o", out, "-lm"])
+    os.remove(obj)
+    os.remove(obj[:-2] + "_o.o")
+    return out
+
+
 if __name__ == "__main__":
     print(build_oracle())

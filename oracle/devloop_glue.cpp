@@ -1,0 +1,76 @@
+/* ORACLE - test infrastructure only.
+ *
+ * Host build of the DEVICE Newton loop: tenscalc_amd/csrc/ipm_newton.hip.inc compiled by g++ with
+ * __device__ defined away, its tape entry points forwarded to the oracle's tape interpreter
+ * (tc_oracle.c) -- the mirror image of ref_glue.c, which does the same for the reference's
+ * lib/ipmPD_CSsolver.c.  tests/test_device_loop_on_host.py runs both loops (and the oracle's own
+ * restatement) on the same tape and inputs and requires identical status, iteration count and
+ * outputs, so the control flow of the device loop is pinned to the reference file without a GPU.
+ */
+#include <math.h>
+#include <stdint.h>
+extern "C" {
+#include "tc_oracle.h"
+}
+
+#include TC_DEFINES_H /* the solver #define block (cmex2optimizeCS.m:303-331), written by oracle/build.py */
+
+#define __device__
+#define __forceinline__ inline
+struct TcCtx {
+  tco_t *g;
+};
+
+#define COPY(fn) static inline void fn(TcCtx &c) { tco_copy(c.g, tco_entry(c.g, #fn)); }
+#define SET(fn) static inline void fn(TcCtx &c, const double *x) { tco_set(c.g, tco_entry(c.g, #fn), x); }
+#define GET1(fn) static inline void fn(TcCtx &c, double *x) { tco_get_flat(c.g, tco_entry(c.g, #fn), x); }
+
+COPY(initPrimal__)
+COPY(initDualEqX__)
+COPY(initDualIneq__)
+COPY(updatePrimalDual__)
+COPY(scaleIneq__)
+COPY(scaleCost__)
+SET(setAddEye2HessianU__)
+SET(setAddEye2HessianEq__)
+SET(setAlphaPrimal__)
+SET(setAlphaDualEq__)
+SET(setAlphaDualIneq__)
+SET(setMu__)
+GET1(getDirectionError__)
+GET1(getScale4Cost__)
+GET1(getNorminf_G__)
+GET1(getNorminf_Grad__)
+GET1(getCurvature__)
+GET1(getMinF_s__)
+static inline void getGapMinFMinLambda__(TcCtx &c, double *gap, double *ineq, double *dual) {
+  double t[3];
+  tco_get_flat(c.g, tco_entry(c.g, "getGapMinFMinLambda__"), t);
+  *gap = t[0];
+  *ineq = t[1];
+  *dual = t[2];
+}
+static inline void getMaxAlphas_s__(TcCtx &c, double *alphaPrimal, double *alphaDual) {
+  double t[2];
+  tco_get_flat(c.g, tco_entry(c.g, "getMaxAlphas_s__"), t);
+  *alphaPrimal = t[0];
+  *alphaDual = t[1];
+}
+static inline void getHessInertia__(TcCtx &c, double *mp, double *mn) {
+  double t[2];
+  tco_get_flat(c.g, tco_entry(c.g, "getHessInertia__"), t);
+  *mp = t[0];
+  *mn = t[1];
+}
+
+#define TC_POW_HALF(x) sqrt(x)
+#include "ipm_newton.hip.inc"
+
+extern "C" void tcdev_solve(tco_t *g, double mu0, int maxIter, double ae0, double ae1, int32_t *status,
+                            int32_t *iter) {
+  TcCtx c = {g};
+  int st = 0, it = 0;
+  ipmPD_CSsolver(c, mu0, maxIter, ae0, ae1, &st, &it);
+  *status = st;
+  *iter = it;
+}

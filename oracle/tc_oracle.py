@@ -128,3 +128,20 @@ class ReferenceLoopOracle(Oracle):
                               ae.ctypes.data_as(_dp), ctypes.byref(st), ctypes.byref(it),
                               ctypes.byref(tm))
         return st.value, it.value
+
+
+class DeviceLoopOracle(Oracle):
+    """Same tape interpreter, but solve() runs the DEVICE Newton loop
+    (tenscalc_amd/csrc/ipm_newton.hip.inc) compiled for the host by oracle/build.py:build_devloop."""
+
+    def __init__(self, tape_path, tag, defines):
+        lib = _build.build_devloop(tag, defines)
+        super().__init__(tape_path, lib=lib)
+        self.L.tcdev_solve.argtypes = [ctypes.c_void_p, ctypes.c_double, ctypes.c_int, ctypes.c_double,
+                                       ctypes.c_double, _i32p, _i32p]
+
+    def solve(self, mu0=1.0, maxIter=200, saveIter=-1, addEye2Hessian=(1e-9, 1e-9)):
+        st, it = ctypes.c_int32(0), ctypes.c_int32(0)
+        self.L.tcdev_solve(self.h, float(mu0), int(maxIter), float(addEye2Hessian[0]),
+                           float(addEye2Hessian[1]), ctypes.byref(st), ctypes.byref(it))
+        return st.value, it.value

@@ -67,11 +67,13 @@ class Printer:
 
     _DEN_POS = {I.I_div: 1, I.I_minus_dot_div: 0, I.I_plus_minus_dot_div: 1, I.I_inv: 0}
 
-    def __init__(self, L, roll=True, recip=False):
+    def __init__(self, L, roll=True, recip=False, fuse=False):
         self.L = L
         self.roll = roll
         self.recip = recip          # x/d -> x*(1/d) with 1/d shared inside a group (opt-in: changes rounding)
         self._rc = {}               # denominator instruction id -> name of its reciprocal in this group
+        self.fuse = fuse            # long sums over the inputs share ONE sweep (see fused_sweeps)
+        self._fused = {}            # sum instruction id -> name of its accumulated value in this group
 
     def _den_leaves(self, t, acc):
         """denominator leaves of every division in tree t"""
@@ -290,11 +292,13 @@ class Printer:
         base = fam.base if fam else None
         delta = fam.delta if fam else None
         # V2: long sums rolled over the term index k_
-        if self.roll and t.typ in (I.I_sumprod, I.I_plus_sqr) and all(isinstance(k, Leaf) for k in t.kids):
+        if (self.roll or self.fuse) and t.typ in (I.I_sumprod, I.I_plus_sqr) and all(isinstance(k, Leaf) for k in t.kids):
             lb = base if fam else [k.idx for k in t.kids]
             ld = delta if fam else [0] * len(t.kids)
             p0 = pos[0] if fam else 0
             tf = Lowering.term_family(t, lb, ld, p0)
+            if tf is not None and not self.roll and any(f[0] not in ("ext", "lit") for f in tf[2]):
+                tf = None       # roll=False: only sums over the inputs stay loops (no indexed access to m[])
             if tf is not None:
                 pos[0] += len(t.kids)
                 return self._term_loop(t, tf)
@@ -317,7 +321,95 @@ class Printer:
             return "(" + self.op_text(t.typ, t.par, r2).replace("TC_DIV", "TC_NUM") + ")*" + rc
         return self.op_text(t.typ, t.par, r)
 
+    # ---- fused sweeps -----------------------------------------------------------------------
+    @staticmethod
+    def _chunks(typ, nf, ns):
+        """[(first term, end term)] of the reference's "m[r]+=" statements (:1003-1012)"""
+        bounds, nSums, k0 = [], 0, 0
+        if typ == I.I_sumprod:
+            for k in range(ns):
+                if k + 1 < ns:
+                    nSums += nf
+                    if nSums >= MAX_TERMS_PERLINE:
+                        bounds.append((k0, k + 1))
+                        k0, nSums = k + 1, 0
+        bounds.append((k0, ns))
+        return bounds
+
+    def _fusable(self, t, acc):
+        if isinstance(t, Leaf):
+            return acc
+        if t.typ in (I.I_sumprod, I.I_plus_sqr) and all(isinstance(k, Leaf) for k in t.kids):
+            tf = Lowering.term_family(t, [k.idx for k in t.kids], [0] * len(t.kids), 0)
+            if tf is not None and all(f[0] in ("ext", "lit") for f in tf[2]) and any(f[0] == "ext" for f in tf[2]):
+                acc.append((t, tf))
+            return acc
+        for k in t.kids:
+            self._fusable(k, acc)
+        return acc
+
+    def fused_sweeps(self, g):
+        """One thread per instance: every long sum of group g whose terms read only the inputs
+        (A'A, A'b, ...) is accumulated in ONE sweep over the term index, so each input element is
+        loaded once per sweep instead of once per sum (36+8 sums over A for hoisted sls: one pass over
+        A instead of nine).  Term order and the reference's chunking of each sum are kept, so the
+        values are those of the separate loops, bit for bit."""
+        L = self.L
+        self._fused = {}
+        if not (self.fuse and L.P == 1):
+            return ""
+        cands = []
+        for u in L.units[g - 1]:
+            if isinstance(u, (Family,)) or not isinstance(u, (int, np.integer)):
+                continue
+            self._fusable(L.tree(int(u)), cands)
+        byn = {}
+        for t, tf in cands:
+            byn.setdefault(tf[1], []).append((t, tf))
+        out = []
+        for ns, lst in byn.items():
+            if len(lst) < 2:
+                continue
+            cuts = {0, ns}
+            info = []
+            for t, (nf, _, facs) in lst:
+                ch = self._chunks(t.typ, nf, ns)
+                info.append((t, nf, facs, ch))
+                for a, b in ch:
+                    cuts.update((a, b))
+                self._fused[t.ins] = f"fs{t.ins}"
+            cuts = sorted(cuts)
+
+            def term(t, facs, kexpr):
+                fs = []
+                for kind, b0, dk, dc, l0 in facs:
+                    if kind == "lit":
+                        fs.append(_lit(l0.val))
+                    else:
+                        fs.append(f"SX({b0}+{dk}*({kexpr}))" if dk else f"SX({b0})")
+                return f"{fs[0]}*{fs[0]}" if t.typ == I.I_plus_sqr else "*".join(fs)
+            w = "  double " + ", ".join(f"fs{t.ins}, fl{t.ins}" for t, *_ in info) + ";\n"
+            for a, b in zip(cuts[:-1], cuts[1:]):
+                w += "  {\n"
+                for t, nf, facs, ch in info:
+                    op = "=" if any(a == c0 for c0, _ in ch) else f"= fl{t.ins} +"
+                    w += f"    fl{t.ins} {op} {term(t, facs, str(a))};\n"
+                if b - a > 1:
+                    w += f"    _Pragma(\"unroll 2\") for (int k_ = {a + 1}; k_ < {b}; k_++) {{\n"
+                    for t, nf, facs, ch in info:
+                        w += f"      fl{t.ins} = fl{t.ins} + {term(t, facs, 'k_')};\n"
+                    w += "    }\n"
+                for t, nf, facs, ch in info:
+                    for q, (c0, c1) in enumerate(ch):
+                        if c1 == b:
+                            w += f"    fs{t.ins} = fl{t.ins};\n" if q == 0 else f"    fs{t.ins} = fs{t.ins} + fl{t.ins};\n"
+                w += "  }\n"
+            out.append(w)
+        return "".join(out)
+
     def _term_loop(self, t, tf):
+        if t.ins in self._fused:
+            return self._fused[t.ins]
         nf, ns, facs = tf
 
         def term(kexpr):
@@ -423,7 +515,7 @@ class Printer:
     def group_body(self, g):
         """HIP statements of dependency group g (1-based)"""
         L = self.L
-        out = []
+        out = [self.fused_sweeps(g)]
         self._rc = {}
         share = set()
         if self.recip:
@@ -495,8 +587,12 @@ def _mask(groups):
 
 def emit_class(spec, fp_contract="fast", block=64, stats=False, roll=True, min_waves=0, lanes=1,
                recip=False, fast_div=False, inline_max=0, reg_budget=150, scratch="auto", body="code",
-               waves=1):
+               waves=1, fuse=False, static_clean=False):
     """Return the HIP source text of the solver class.
+
+    static_clean=True: tests and code of dependency groups that are certainly clean at an entry
+    point's call sites in the Newton loop are left out there (loop_schedule.py); unelided twins
+    ``<entry>_full`` serve the probe kernel and getOutputs.
 
     body="code": dependency groups are printed as HIP statements (the lowering of lowering.py).
     body="interp": the groups stay DATA -- a word stream walked in lock step by every lane of a
@@ -521,7 +617,7 @@ def emit_class(spec, fp_contract="fast", block=64, stats=False, roll=True, min_w
         L = Lowering(T, getattr(spec, "code", None), roll=roll, lanes=lanes)
     if block % lanes:
         raise ValueError("block must be a multiple of lanes")
-    P = Printer(L, roll=roll, recip=recip)
+    P = Printer(L, roll=roll, recip=recip, fuse=fuse)
     cls = spec.classname
     nW = max(1, (T.nGroups + 63) // 64)
     w = []
@@ -702,20 +798,27 @@ def emit_class(spec, fp_contract="fast", block=64, stats=False, roll=True, min_w
                 w.append(f"  MM({L.pslot[i]}) = input[{k}];\n")
         w.append(inval(e["children"]))
         w.append("}\n")
+    elide = {}
+    if static_clean and not interp:
+        from .loop_schedule import certainly_clean
+        elide = certainly_clean(T, spec.defines)
+    full = "_full" if elide else ""       # name suffix of the context-free twins
     for e in T.gets:
         args = ", ".join(f"double *y{k + 1}" for k in range(len(e["outputs"])))
-        w.append(f"static __device__ __forceinline__ void {e['name']}(TcCtx &c, {args}) {{\n  TC_UNPACK\n")
+        for sfx, skip in (("", elide.get(e["name"], set())),) + ((("_full", set()),) if elide else ()):
+            w.append(f"static __device__ __forceinline__ void {e['name']}{sfx}(TcCtx &c, {args}) {{\n  TC_UNPACK\n")
+            for g in e["parents"]:
+                if g not in Dg and g not in skip:
+                    w.append(f"  TC_NEED({g});\n")
+            for k, o in enumerate(e["outputs"]):
+                for j, i in enumerate(o["ins"]):
+                    w.append(f"  y{k + 1}[{j}] = {P.ref(i)};\n")
+            w.append("}\n")
+    for e, sfx, skip in [(e, sfx, skip) for e in T.copies
+                         for sfx, skip in ((("", elide.get(e["name"], set())),) + ((("_full", set()),) if elide else ()))]:
+        w.append(f"static __device__ __forceinline__ void {e['name']}{sfx}(TcCtx &c) {{\n  TC_UNPACK\n")
         for g in e["parents"]:
-            if g not in Dg:
-                w.append(f"  TC_NEED({g});\n")
-        for k, o in enumerate(e["outputs"]):
-            for j, i in enumerate(o["ins"]):
-                w.append(f"  y{k + 1}[{j}] = {P.ref(i)};\n")
-        w.append("}\n")
-    for e in T.copies:
-        w.append(f"static __device__ __forceinline__ void {e['name']}(TcCtx &c) {{\n  TC_UNPACK\n")
-        for g in e["parents"]:
-            if g not in Dg:
+            if g not in Dg and g not in skip:
                 w.append(f"  TC_NEED({g});\n")
         pairs = []
         if interp:
@@ -800,7 +903,7 @@ def emit_class(spec, fp_contract="fast", block=64, stats=False, roll=True, min_w
     else:
         for k, o in enumerate(outs):
             w.append(f"  double y{k + 1}[{max(1, len(o['ins']))}];\n")
-        w.append(f"  {cls}_getOutputs(c, " + ", ".join(f"y{k + 1}" for k in range(len(outs))) + ");\n")
+        w.append(f"  {cls}_getOutputs{full}(c, " + ", ".join(f"y{k + 1}" for k in range(len(outs))) + ");\n")
         w.append("  if (c.lane != 0) return;\n")
         for k, o in enumerate(outs):
             n_ = len(o["ins"])
@@ -817,10 +920,10 @@ def emit_class(spec, fp_contract="fast", block=64, stats=False, roll=True, min_w
              "tc_probe_kernel(const double *__restrict__ S, const double *__restrict__ Sd, double *__restrict__ out,\n"
              "                int which, double mu0, double ae0, double ae1, long B, double *__restrict__ Mg) {\n" + prologue +
              "#if setAddEye2Hessian != 0\n  setAddEye2HessianU__(c, &ae0);\n  setAddEye2HessianEq__(c, &ae1);\n#endif\n"
-             "  initPrimal__(c);\n"
-             "#if scaleCost != 0\n  scaleCost__(c);\n#endif\n"
-             "#if nF > 0\n#if scaleInequalities != 0\n  scaleIneq__(c);\n#endif\n  setMu__(c, &mu0);\n  initDualIneq__(c);\n#endif\n"
-             "#if nG > 0\n  initDualEqX__(c);\n#endif\n"
+             f"  initPrimal__{full}(c);\n"
+             f"#if scaleCost != 0\n  scaleCost__{full}(c);\n#endif\n"
+             f"#if nF > 0\n#if scaleInequalities != 0\n  scaleIneq__{full}(c);\n#endif\n  setMu__(c, &mu0);\n  initDualIneq__{full}(c);\n#endif\n"
+             f"#if nG > 0\n  initDualEqX__{full}(c);\n#endif\n"
              "  switch (which) {\n")
     probes = []
     for k, e in enumerate(T.gets):
@@ -829,7 +932,7 @@ def emit_class(spec, fp_contract="fast", block=64, stats=False, roll=True, min_w
         w.append(f"    case {k}: {{\n")
         for q, o in enumerate(e["outputs"]):
             w.append(f"      double y{q + 1}[{max(1, len(o['ins']))}];\n")
-        w.append(f"      {e['name']}(c, " + ", ".join(f"y{q + 1}" for q in range(len(e["outputs"]))) + ");\n")
+        w.append(f"      {e['name']}{full}(c, " + ", ".join(f"y{q + 1}" for q in range(len(e["outputs"]))) + ");\n")
         po = 0
         for q, o in enumerate(e["outputs"]):
             n_ = len(o["ins"])
@@ -922,7 +1025,7 @@ def class_header(spec):
 def build_class(spec, fp_contract="fast", arch="gfx950", opt="-O3", block=64, force=False,
                 outdir=None, stats=False, tag=None, extra_flags=(), roll=True, min_waves=0, lanes=1,
                 recip=False, fast_div=False, inline_max=0, reg_budget=150, scratch="auto", body="code",
-                waves=1):
+                waves=1, fuse=False, static_clean=False):
     """Emit <cls>.hip (+ <cls>.h, <cls>.tape) and compile lib<cls>.so with hipcc for gfx950.
     Mirrors the createGateway/compile step of cmex2optimizeCS.m:403-417."""
     from .tapeio import save_tape
@@ -932,7 +1035,8 @@ def build_class(spec, fp_contract="fast", arch="gfx950", opt="-O3", block=64, fo
     suffix = f"_{tag}" if tag else ""
     src, L = emit_class(spec, fp_contract=fp_contract, block=block, stats=stats, roll=roll,
                         min_waves=min_waves, lanes=lanes, recip=recip, fast_div=fast_div, inline_max=inline_max,
-                        reg_budget=reg_budget, scratch=scratch, body=body, waves=waves)
+                        reg_budget=reg_budget, scratch=scratch, body=body, waves=waves, fuse=fuse,
+                        static_clean=static_clean)
     hip = os.path.join(outdir, f"{cls}{suffix}.hip")
     so = os.path.join(outdir, f"lib{cls}{suffix}.so")
     flags = [opt, f"--offload-arch={arch}", "-fPIC", "-shared", "-std=c++17",

@@ -87,8 +87,13 @@ class Hoister:
         r = self._memo.get(f.idx)
         if r is not None:
             return r
-        if not f.args or self.is_slow(f) or f.op in ("ldl", "ldl_d", "ldl_l", "mldivide"):
+        if not f.args or f.op in ("ldl", "ldl_d", "ldl_l", "mldivide"):
             r = f
+        elif self.is_slow(f):
+            r = self._split_scalars(f) if f.op == "tprod" else f
+            if r is f and f.op != "tprod":
+                na = [self.rewrite(a) for a in f.args]
+                r = f if all(x is y for x, y in zip(na, f.args)) else tc._rebuild(f, na)
         else:
             na = [self.rewrite(a) for a in f.args]
             r = f if all(x is y for x, y in zip(na, f.args)) else tc._rebuild(f, na)
@@ -97,6 +102,23 @@ class Hoister:
         self._memo[f.idx] = r
         self._memo[r.idx] = r
         return r
+
+    def _split_scalars(self, f):
+        """slow c*tprod(A,B,..) -> c*(tprod(A,B,..)): the same canonical form _reassociate gives its
+        slow block, so e.g. the Hessian 2*A'A and the hoisted gradient coefficient share one A'A"""
+        inds, _ = f.par
+        scal = [k for k, o in enumerate(f.args) if o.size == ()]
+        big = [k for k, o in enumerate(f.args) if o.size != ()]
+        if not scal or len(big) < 2 or not self.has_param(f):
+            return f
+        margs = []
+        for k in big:
+            margs += [f.args[k], inds[k]]
+        M = tc.tprod(*margs)
+        sargs = []
+        for k in scal:
+            sargs += [f.args[k], ()]
+        return tc.tprod(*(sargs + [M, tuple(range(1, M.ndim + 1))]))
 
     def _improve(self, f):
         best, cbest = f, self.fast_cost(f)
@@ -157,10 +179,18 @@ class Hoister:
         inner_l = [i for i in slow_labels if i < 0 and i not in fast_labels]
         mmap = {i: n + 1 for n, i in enumerate(sorted(outer_l, key=lambda i: (i < 0, abs(i))))}
         mmap.update({i: -(n + 1) for n, i in enumerate(inner_l)})
+        # the contraction of the non-scalar slow factors first, scalar factors applied to its (few)
+        # entries afterwards: sum_k A_ki*A_kj*2 would cost one more multiplication per term
         margs = []
-        for k in slow:
+        for k in big:
             margs += [objs[k], tuple(mmap[i] for i in labs[k])]
         M = tc.tprod(*margs)
+        scal = [k for k in slow if objs[k].size == ()]
+        if scal:
+            sargs = []
+            for k in scal:
+                sargs += [objs[k], ()]
+            M = tc.tprod(*(sargs + [M, tuple(range(1, M.ndim + 1))]))
         m_out = tuple(sorted(outer_l, key=lambda i: mmap[i]))
         # renumber the summation labels that survive in the outer product
         keep_neg = []

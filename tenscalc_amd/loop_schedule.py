@@ -1,0 +1,133 @@
+"""Which dependency groups are certainly clean at each entry-point call of the Newton loop.
+
+The reference evaluates dependency groups lazily: every ``get``/``copy`` tests the status flag of
+each group it needs (writeCfunctionpergroup.m:653-657) and evaluates the dirty ones.  The printed-code
+back-ends inline the groups into the entry points and the entry points into the loop, so a group
+needed by k entry points is k copies of its code in the kernel -- although the loop calls the entry
+points in a fixed order and, e.g., the KKT factorisation evaluated for ``getCurvature__`` is always
+still clean when ``getDirectionError__``, ``getMaxAlphas_s__``, ``getMinF_s__`` and
+``updatePrimalDual__`` need it.
+
+This module restates the call structure of csrc/ipm_newton.hip.inc (one call site per get, loops
+and conditionals only -- no arithmetic) and runs a forward "must be clean" data-flow analysis over
+it: a group is *certainly clean* at a call site if on every path reaching the site it has been
+evaluated after the last set/copy that could invalidate it.  Such a group needs neither its test
+nor its code at that site.  The flags stay in the program for everything else, so the analysis
+only has to be sound, not complete; ``hip_emitter`` keeps unelided twins of all entry points for
+the probe kernel and for getOutputs, which run outside the loop's context.
+
+Soundness is checked end to end: the ``strict`` class is built WITH the elision and must remain
+bit-identical to the oracle (which keeps the dynamic flags) on every GPU parity test.
+"""
+from __future__ import annotations
+
+__all__ = ["newton_program", "certainly_clean"]
+
+
+def newton_program(d):
+    """Call structure of ipmPD_CSsolver() in csrc/ipm_newton.hip.inc for the #define block ``d``.
+    Nodes: ("call", name) | ("if", [nodes]) | ("loop", [nodes]) | ("exit",).  A loop that contains
+    ("exit",) markers is left only there; a loop without markers may be left after any statement."""
+    nF, nG = int(d["nF"]), int(d["nG"])
+    call = lambda n: ("call", n)                                    # noqa: E731
+    P = []
+    if d["setAddEye2Hessian"]:
+        P += [call("setAddEye2HessianU__"), call("setAddEye2HessianEq__")]
+    P.append(call("initPrimal__"))
+    if d["scaleCost"]:
+        P += [call("scaleCost__"), call("getScale4Cost__")]
+    if nF > 0:
+        if d["scaleInequalities"]:
+            P.append(call("scaleIneq__"))
+        P += [call("setMu__"), call("initDualIneq__")]
+    if nG > 0:
+        P.append(call("initDualEqX__"))
+    body = [call("getNorminf_Grad__")]
+    if nG > 0:
+        body.append(call("getNorminf_G__"))
+    if nF > 0:
+        body.append(call("getGapMinFMinLambda__"))
+    if d["setAddEye2Hessian"] and d["adjustAddEye2Hessian"]:
+        body += [("if", [call("setAddEye2HessianU__")]), ("if", [call("setAddEye2HessianEq__")])]
+        inner = [call("getCurvature__")]
+        if d["useInertia"]:
+            inner.append(("if", [call("getHessInertia__")]))
+        inner.append(call("getDirectionError__"))
+        # left after pass 1, when the curvature test passes, or when no regularisation changed: in all
+        # three cases before any set of this pass; after a set the loop continues with pass 1
+        inner.append(("exit",))
+        inner.append(("if", [call("setAddEye2HessianU__")]))
+        inner.append(("if", [call("setAddEye2HessianEq__")]))
+        body.append(("loop", inner))
+    if nF == 0:
+        body.append(call("setAlphaPrimal__"))
+        if nG > 0:
+            body.append(call("setAlphaDualEq__"))
+        body.append(call("updatePrimalDual__"))
+    else:
+        body.append(call("getMaxAlphas_s__"))
+        body.append(("loop", [call("setAlphaPrimal__"), ("if", [call("getMinF_s__")])]))
+        if nG > 0:
+            body.append(call("setAlphaDualEq__"))
+        body += [call("setAlphaDualIneq__"), call("updatePrimalDual__"),
+                 ("if", [call("setMu__")]), ("if", [call("setMu__"), call("initDualIneq__")]),
+                 ("if", [call("setMu__")])]
+    P.append(("loop", body))
+    return P
+
+
+def certainly_clean(tape, defines):
+    """{entry name: set of groups (1-based) that are clean at EVERY call of that entry in the loop}."""
+    ent = {}
+    for e in tape.sets:
+        ent[e["name"]] = ("set", (), tuple(e["children"]))
+    for e in tape.gets:
+        ent[e["name"]] = ("get", tuple(e["parents"]), ())
+    for e in tape.copies:
+        ent[e["name"]] = ("copy", tuple(e["parents"]), tuple(e["children"]))
+    sites = {}           # entry name -> intersection over its call sites of the clean set seen there
+
+    def run(nodes, clean, record):
+        for nd in nodes:
+            if nd[0] == "call":
+                kind, parents, children = ent.get(nd[1], ("none", (), ()))
+                if parents:
+                    if record:
+                        seen = clean & set(parents)
+                        sites[nd[1]] = seen if nd[1] not in sites else sites[nd[1]] & seen
+                    clean = clean | set(parents)
+                if children:
+                    clean = clean - set(children)
+            elif nd[0] == "if":
+                clean = clean & run(nd[1], clean, record)
+            elif nd[0] == "loop":  # any number of passes
+                head = clean
+                while True:
+                    out = run(nd[1], head, False)
+                    new = head & out
+                    if new == head:
+                        break
+                    head = new
+                run(nd[1], head, record)
+                marks = [k for k, x in enumerate(nd[1]) if x[0] == "exit"]
+                if marks:      # left only at the markers (at least one pass)
+                    st = [run(nd[1][:k], head, False) for k in marks]
+                    clean = frozenset.intersection(*[frozenset(x) for x in st])
+                else:          # what is clean at EVERY point of the body (break anywhere, zero passes too)
+                    clean = head & _everywhere(nd[1], head, run)
+            elif nd[0] == "exit":
+                pass
+        return clean
+
+    run(newton_program(defines), frozenset(), True)
+    return {k: set(v) for k, v in sites.items()}
+
+
+def _everywhere(nodes, clean, run):
+    acc = clean
+    for k in range(len(nodes)):
+        clean_k = run(nodes[:k + 1], clean, False)
+        acc = acc & clean_k
+        if nodes[k][0] in ("if", "loop"):
+            acc = acc & _everywhere(nodes[k][1], run(nodes[:k], clean, False), run)
+    return acc
