@@ -736,6 +736,8 @@ def emit_class(spec, fp_contract="fast", block=64, stats=False, roll=True, min_w
             w.append(f"static __device__ __noinline__ void tc_grp{g}(tc_mem m, tc_glob S, const long B, const int lane) {{\n")
             w.append(P.group_body(g))
             w.append(f"}}\n#define TC_CALL_GRP{g} tc_grp{g}(c.m, c.S, c.B, c.lane)\n")
+    w.append("\n// TC_EVAL: the group is certainly dirty here (loop_schedule.py): evaluate without testing the flag\n"
+             "#define TC_EVAL(g) do { c.st[((g)-1)>>6] |= 1ull << (((g)-1)&63); TC_CALL_GRP##g; } while (0)\n")
     w.append("\n#ifndef TC_STATS\n#define TC_NEED(g) do { if (!((c.st[((g)-1)>>6] >> (((g)-1)&63)) & 1ull)) { "
              "c.st[((g)-1)>>6] |= 1ull << (((g)-1)&63); TC_CALL_GRP##g; } } while (0)\n"
              "#else  // diagnostic build: wall cycles (s_memtime) and call count per dependency group\n"
@@ -798,28 +800,35 @@ def emit_class(spec, fp_contract="fast", block=64, stats=False, roll=True, min_w
                 w.append(f"  MM({L.pslot[i]}) = input[{k}];\n")
         w.append(inval(e["children"]))
         w.append("}\n")
-    elide = {}
+    elide, sure = {}, {}
     if static_clean and not interp:
-        from .loop_schedule import certainly_clean
-        elide = certainly_clean(T, spec.defines)
+        from .loop_schedule import analyse
+        elide, sure = analyse(T, spec.defines)
     full = "_full" if elide else ""       # name suffix of the context-free twins
+
+    def need(g, name, sfx):
+        """evaluation of group g inside entry point `name`: nothing where it is certainly clean, no flag
+        test where it is certainly dirty (TC_EVAL), the reference's lazy test otherwise"""
+        if g in Dg or (not sfx and g in elide.get(name, ())):
+            return ""
+        if not sfx and g in sure.get(name, ()):
+            return f"  TC_EVAL({g});\n"
+        return f"  TC_NEED({g});\n"
+
     for e in T.gets:
         args = ", ".join(f"double *y{k + 1}" for k in range(len(e["outputs"])))
-        for sfx, skip in (("", elide.get(e["name"], set())),) + ((("_full", set()),) if elide else ()):
+        for sfx in ("", "_full") if elide else ("",):
             w.append(f"static __device__ __forceinline__ void {e['name']}{sfx}(TcCtx &c, {args}) {{\n  TC_UNPACK\n")
             for g in e["parents"]:
-                if g not in Dg and g not in skip:
-                    w.append(f"  TC_NEED({g});\n")
+                w.append(need(g, e["name"], "x" if not elide else sfx))
             for k, o in enumerate(e["outputs"]):
                 for j, i in enumerate(o["ins"]):
                     w.append(f"  y{k + 1}[{j}] = {P.ref(i)};\n")
             w.append("}\n")
-    for e, sfx, skip in [(e, sfx, skip) for e in T.copies
-                         for sfx, skip in ((("", elide.get(e["name"], set())),) + ((("_full", set()),) if elide else ()))]:
+    for e, sfx in [(e, sfx) for e in T.copies for sfx in (("", "_full") if elide else ("",))]:
         w.append(f"static __device__ __forceinline__ void {e['name']}{sfx}(TcCtx &c) {{\n  TC_UNPACK\n")
         for g in e["parents"]:
-            if g not in Dg and g not in skip:
-                w.append(f"  TC_NEED({g});\n")
+            w.append(need(g, e["name"], "x" if not elide else sfx))
         pairs = []
         if interp:
             w.append(f"  tc_interp(c.m, {cs['rid'][e['name']]});\n")
@@ -853,6 +862,14 @@ def emit_class(spec, fp_contract="fast", block=64, stats=False, roll=True, min_w
         w.append(inval(e["children"]))
         w.append("}\n")
     # entry points the loop may reference under #if but that this problem does not have
+    if elide and lanes == 1 and scratch == "private" and not roll:
+        # state promoted to registers: tell the compiler that what the groups certainly dirty at the head
+        # of the Newton loop computed last iteration is dead (never read before it is recomputed)
+        from .loop_schedule import analyse as _an
+        slots = sorted({int(L.pslot[int(i)]) for g in _an.loop_head_dirty for i in T.groups[g - 1]
+                        if L.pslot[int(i)] >= 0})
+        w.append("#define TC_LOOP_HEAD_KILL { tc_mem m = c.m; " +
+                 " ".join(f"m[{k}] = __builtin_nondeterministic_value(m[{k}]);" for k in slots) + " }\n")
     w.append("\n#define TC_POW_HALF(x) sqrt(x)\n")
     w.append(f'#include "ipm_newton.hip.inc"\n\n')
     # kernels -------------------------------------------------------------------------------

@@ -21,7 +21,7 @@ bit-identical to the oracle (which keeps the dynamic flags) on every GPU parity 
 """
 from __future__ import annotations
 
-__all__ = ["newton_program", "certainly_clean"]
+__all__ = ["newton_program", "certainly_clean", "analyse"]
 
 
 def newton_program(d):
@@ -78,56 +78,71 @@ def newton_program(d):
 
 def certainly_clean(tape, defines):
     """{entry name: set of groups (1-based) that are clean at EVERY call of that entry in the loop}."""
+    return analyse(tape, defines)[0]
+
+
+def analyse(tape, defines):
+    """(clean, dirty): per entry point, the groups that are certainly clean / certainly dirty at
+    every one of its call sites.  A certainly dirty group is evaluated there without testing its
+    flag -- which also tells the compiler that last iteration's values of that group are dead."""
     ent = {}
     for e in tape.sets:
-        ent[e["name"]] = ("set", (), tuple(e["children"]))
+        ent[e["name"]] = (frozenset(), frozenset(e["children"]))
     for e in tape.gets:
-        ent[e["name"]] = ("get", tuple(e["parents"]), ())
+        ent[e["name"]] = (frozenset(e["parents"]), frozenset())
     for e in tape.copies:
-        ent[e["name"]] = ("copy", tuple(e["parents"]), tuple(e["children"]))
-    sites = {}           # entry name -> intersection over its call sites of the clean set seen there
+        ent[e["name"]] = (frozenset(e["parents"]), frozenset(e["children"]))
+    sites_c, sites_d = {}, {}
+    heads = []           # fixpoint state at the head of every loop, outermost last
 
-    def run(nodes, clean, record):
+    def meet(a, b):
+        return (a[0] & b[0], a[1] & b[1])
+
+    def run(nodes, st, record):
+        clean, dirty = st
         for nd in nodes:
             if nd[0] == "call":
-                kind, parents, children = ent.get(nd[1], ("none", (), ()))
+                parents, children = ent.get(nd[1], (frozenset(), frozenset()))
                 if parents:
                     if record:
-                        seen = clean & set(parents)
-                        sites[nd[1]] = seen if nd[1] not in sites else sites[nd[1]] & seen
-                    clean = clean | set(parents)
+                        sc, sd = clean & parents, dirty & parents
+                        sites_c[nd[1]] = sc if nd[1] not in sites_c else sites_c[nd[1]] & sc
+                        sites_d[nd[1]] = sd if nd[1] not in sites_d else sites_d[nd[1]] & sd
+                    clean, dirty = clean | parents, dirty - parents
                 if children:
-                    clean = clean - set(children)
+                    clean, dirty = clean - children, dirty | children
             elif nd[0] == "if":
-                clean = clean & run(nd[1], clean, record)
+                clean, dirty = meet((clean, dirty), run(nd[1], (clean, dirty), record))
             elif nd[0] == "loop":  # any number of passes
-                head = clean
+                head = (clean, dirty)
                 while True:
-                    out = run(nd[1], head, False)
-                    new = head & out
+                    new = meet(head, run(nd[1], head, False))
                     if new == head:
                         break
                     head = new
                 run(nd[1], head, record)
+                if record:
+                    heads.append(head)
                 marks = [k for k, x in enumerate(nd[1]) if x[0] == "exit"]
                 if marks:      # left only at the markers (at least one pass)
-                    st = [run(nd[1][:k], head, False) for k in marks]
-                    clean = frozenset.intersection(*[frozenset(x) for x in st])
-                else:          # what is clean at EVERY point of the body (break anywhere, zero passes too)
-                    clean = head & _everywhere(nd[1], head, run)
-            elif nd[0] == "exit":
-                pass
-        return clean
+                    sts = [run(nd[1][:k], head, False) for k in marks]
+                    clean, dirty = sts[0]
+                    for x in sts[1:]:
+                        clean, dirty = meet((clean, dirty), x)
+                else:          # what holds at EVERY point of the body (break anywhere, zero passes too)
+                    clean, dirty = meet(head, _everywhere(nd[1], head, run, meet))
+        return (clean, dirty)
 
-    run(newton_program(defines), frozenset(), True)
-    return {k: set(v) for k, v in sites.items()}
+    allg = frozenset(range(1, tape.nGroups + 1))
+    run(newton_program(defines), (frozenset(), allg), True)
+    analyse.loop_head_dirty = set(heads[-1][1]) if heads else set()   # at the head of the Newton loop itself
+    return {k: set(v) for k, v in sites_c.items()}, {k: set(v) for k, v in sites_d.items()}
 
 
-def _everywhere(nodes, clean, run):
-    acc = clean
+def _everywhere(nodes, st, run, meet):
+    acc = st
     for k in range(len(nodes)):
-        clean_k = run(nodes[:k + 1], clean, False)
-        acc = acc & clean_k
+        acc = meet(acc, run(nodes[:k + 1], st, False))
         if nodes[k][0] in ("if", "loop"):
-            acc = acc & _everywhere(nodes[k][1], run(nodes[:k], clean, False), run)
+            acc = meet(acc, _everywhere(nodes[k][1], run(nodes[:k], st, False), run, meet))
     return acc

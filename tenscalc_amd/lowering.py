@@ -165,6 +165,22 @@ class Lowering:
                     continue
                 seen.add(key)
                 cands.append(ins)
+        if P > 1:
+            # an element-wise tensor node whose only reader is a reduction (y = A*x-b read by norm2 alone,
+            # once the gradient no longer needs it) would be inlined into that reduction term by term;
+            # keep it a family so that it can be distributed over the lanes with its operands
+            long_sum = {}        # operand -> the long I_plus_sqr / I_sumprod that reads it
+            for i in range(1, n + 1):
+                if T.used[i] and grp[i] > 0 and T.types[i - 1] in (I.I_plus_sqr, I.I_sumprod) \
+                        and ost[i] - ost[i - 1] >= 2 * P:
+                    for j in opl[ost[i - 1]:ost[i]]:
+                        long_sum[j] = i
+            for ins in cands:
+                if (ins.size >= 2 * P and self.inline[ins].all()
+                        and len({long_sum.get(int(i), -int(i)) for i in ins}) == 1 and int(ins[0]) in long_sum
+                        and all(any(int(j) in self.dval for j in opl[ost[int(i) - 1]:ost[int(i)]]) for i in ins)):
+                    self.inline[ins] = False
+                    self.local[ins] = True
         fam_members = []
         for ins in cands:
             m = self._family_precheck(ins)
