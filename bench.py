@@ -150,7 +150,10 @@ def main():
                          "frac": achieved / HBM_PEAK_GBPS, "traffic": measured_traffic(args.variant, B),
                          "kernel": "tc_solve_kernel", "kernel_ms_avg": kavg * 1e3,
                          "algorithmic_bytes_per_launch": ALGO_BYTES_PER_SOLVE * B,
-                         "algorithmic_bytes_per_solve": ALGO_BYTES_PER_SOLVE},
+                         "algorithmic_bytes_per_solve": ALGO_BYTES_PER_SOLVE,
+                         # this path is sparse scalar fp64 work, so the vector-fp64 fraction is
+                         # reported beside the HBM fraction the north star asks for
+                         "fp64_valu": tape_flops(spec, it, B, kavg)},
         }
         if not args.no_cpu and world == 1:      # CPU baseline: rank 0 at N=1 only
             # always the reference's own tape (never the hoisted one): that is the path the reference runs
@@ -160,6 +163,38 @@ def main():
         dist.barrier(device_ids=[local])
         dist.destroy_process_group()
     obj.close()
+
+
+FP64_VALU_PEAK_TFLOPS = 78.6       # MI355X_MICROARCH.md: vector fp64 (no MFMA on this path)
+
+
+def tape_flops(spec, it, B, kernel_s):
+    """Algorithmic flops of one launch from the tape's static per-group flop classes (the accounting of
+    examples/flops.m:97-99 / instructionsTableUTHash.c:816-832): groups that depend on parameters only are
+    evaluated once per solve, every other group once per Newton iteration, the groups behind
+    getMinF_s__ once more per extra line-search trial (2 trials per iteration on this workload, measured with
+    the stats build).  An estimate of useful work, not a counter."""
+    T = spec.tape
+    loop_sets = {"updatePrimalDual__", "setMu__", "setAlphaPrimal__", "setAlphaDualIneq__", "setAlphaDualEq__",
+                 "setAddEye2HessianU__", "setAddEye2HessianEq__", "initDualIneq__", "initPrimal__"}
+    varying = set()
+    for e in list(T.sets) + list(T.copies):
+        if e["name"] in loop_sets:
+            varying |= set(e["children"])
+    used = set()
+    for e in list(T.gets) + list(T.copies):
+        if e["name"] not in ("getGrad__", "getHessInertia__", "getJ__"):
+            used |= set(e["parents"])
+    once = sum(int(T.flops[g].sum()) for g in used if g not in varying)
+    per_iter = sum(int(T.flops[g].sum()) for g in used if g in varying)
+    minf = [e for e in T.gets if e["name"] == "getMinF_s__"]
+    alpha = [e for e in T.sets if e["name"] == "setAlphaPrimal__"]
+    trial = sum(int(T.flops[g].sum()) for g in (set(minf[0]["parents"]) & set(alpha[0]["children"]))) if minf and alpha else 0
+    iters = float(it.mean())
+    per_solve = once + iters * (per_iter + trial)
+    tf = per_solve * B / kernel_s / 1e12
+    return {"flops_per_solve": per_solve, "achieved": tf, "peak": FP64_VALU_PEAK_TFLOPS, "unit": "TFLOP/s",
+            "frac": tf / FP64_VALU_PEAK_TFLOPS}
 
 
 def measured_traffic(variant, B):

@@ -74,6 +74,14 @@ class Printer:
         self._rc = {}               # denominator instruction id -> name of its reciprocal in this group
         self.fuse = fuse            # long sums over the inputs share ONE sweep (see fused_sweeps)
         self._fused = {}            # sum instruction id -> name of its accumulated value in this group
+        # store->load forwarding inside a group (lanes>1): a value just written to LDS by this lane is
+        # read back from the register that holds it -- a replicated value by every later statement of
+        # the group, element c_ of a lane-split family by the aligned member c_ of a later family --
+        # instead of through an LDS round trip the compiler cannot remove (it does not know that the
+        # other lanes of the instance write other slots)
+        self.forward = False
+        self._fw_rep = {}           # slot -> name of the register copy (replicated values)
+        self._fw_fam = {}           # (first slot, slot stride) -> (name prefix of per-block copies, members)
 
     def _den_leaves(self, t, acc):
         """denominator leaves of every division in tree t"""
@@ -307,8 +315,16 @@ class Printer:
             if isinstance(k, Leaf):
                 j = pos[0]
                 pos[0] += 1
-                r.append(self.leaf_text(k, base[j] if fam else None, delta[j] if fam else 0,
-                                        var=fam.var if fam else "c_"))
+                fw = None
+                if self.forward and k.kind == "priv":
+                    b_, d_ = (base[j], delta[j]) if fam else (k.idx, 0)
+                    if d_ == 0:
+                        fw = self._fw_rep.get(b_)
+                    elif fam is not None and fam.var == "c_" and (b_, d_) in self._fw_fam \
+                            and fam.n <= self._fw_fam[(b_, d_)][1]:
+                        fw = "@FW" + self._fw_fam[(b_, d_)][0] + "@"          # per-block name, see group_body
+                r.append(fw or self.leaf_text(k, base[j] if fam else None, delta[j] if fam else 0,
+                                              var=fam.var if fam else "c_"))
             else:
                 r.append("(" + self.expr(k, fam, pos) + ")")
         p = self._DEN_POS.get(t.typ)
@@ -517,6 +533,7 @@ class Printer:
         L = self.L
         out = [self.fused_sweeps(g)]
         self._rc = {}
+        self._fw_rep, self._fw_fam = {}, {}
         share = set()
         if self.recip:
             cnt = {}
@@ -535,7 +552,18 @@ class Printer:
             if isinstance(u, Family):
                 e = self.expr(u.template, u)
                 dst = f"{u.dst0}+c_" if u.ddst == 1 else f"{u.dst0}+({u.ddst})*c_"
-                if L.P > 1:
+                if L.P > 1 and self.forward and u.var == "c_":
+                    nm = f"fw{u.dst0}"
+                    nb = -(-u.n // L.P)
+                    out.append("  double " + ", ".join(f"{nm}_{k}" for k in range(nb)) + ";\n")
+                    for k in range(nb):
+                        import re as _re
+                        ek = _re.sub(r"@FW(\w+)@", lambda m_: f"{m_.group(1)}_{k}", e)
+                        guard = "" if (k + 1) * L.P <= u.n else f"if (c_ < {u.n}) "
+                        out.append(f"  {{ const int c_ = lane + {k * L.P}; {guard}{{ {nm}_{k} = {ek}; MM({dst}) = {nm}_{k}; }} }}\n")
+                    out.append("  __builtin_amdgcn_wave_barrier();\n")
+                    self._fw_fam[(u.dst0, u.ddst)] = (nm, u.n)
+                elif L.P > 1:
                     # the lanes sharing the instance split the members; LDS (in order within a
                     # wave) makes every element visible to all of them afterwards
                     out.append(self.lane_loop("c_", u.n, f"MM({dst}) = {e};") +
@@ -552,8 +580,13 @@ class Printer:
             e = self.expr(L.tree(i))
             if L.local[i]:
                 out.append(f"  const double t{i} = {e};\n")
+            elif self.forward and L.P > 1:
+                k_ = int(L.pslot[i])
+                out.append(f"  const double r{k_}_ = {e};\n  MM({k_}) = r{k_}_;\n")
+                self._fw_rep[k_] = f"r{k_}_"
             else:
                 out.append(f"  MM({L.pslot[i]}) = {e};\n")
+        self._fw_rep, self._fw_fam = {}, {}
         return "".join(out)
 
     def lane_loop(self, var, n, body):
@@ -587,7 +620,7 @@ def _mask(groups):
 
 def emit_class(spec, fp_contract="fast", block=64, stats=False, roll=True, min_waves=0, lanes=1,
                recip=False, fast_div=False, inline_max=0, reg_budget=150, scratch="auto", body="code",
-               waves=1, fuse=False, static_clean=False):
+               waves=1, fuse=False, static_clean=False, forward=False):
     """Return the HIP source text of the solver class.
 
     static_clean=True: tests and code of dependency groups that are certainly clean at an entry
@@ -618,6 +651,7 @@ def emit_class(spec, fp_contract="fast", block=64, stats=False, roll=True, min_w
     if block % lanes:
         raise ValueError("block must be a multiple of lanes")
     P = Printer(L, roll=roll, recip=recip, fuse=fuse)
+    P.forward = bool(forward) and lanes > 1
     cls = spec.classname
     nW = max(1, (T.nGroups + 63) // 64)
     w = []
@@ -1042,7 +1076,7 @@ def class_header(spec):
 def build_class(spec, fp_contract="fast", arch="gfx950", opt="-O3", block=64, force=False,
                 outdir=None, stats=False, tag=None, extra_flags=(), roll=True, min_waves=0, lanes=1,
                 recip=False, fast_div=False, inline_max=0, reg_budget=150, scratch="auto", body="code",
-                waves=1, fuse=False, static_clean=False):
+                waves=1, fuse=False, static_clean=False, forward=False):
     """Emit <cls>.hip (+ <cls>.h, <cls>.tape) and compile lib<cls>.so with hipcc for gfx950.
     Mirrors the createGateway/compile step of cmex2optimizeCS.m:403-417."""
     from .tapeio import save_tape
@@ -1053,7 +1087,7 @@ def build_class(spec, fp_contract="fast", arch="gfx950", opt="-O3", block=64, fo
     src, L = emit_class(spec, fp_contract=fp_contract, block=block, stats=stats, roll=roll,
                         min_waves=min_waves, lanes=lanes, recip=recip, fast_div=fast_div, inline_max=inline_max,
                         reg_budget=reg_budget, scratch=scratch, body=body, waves=waves, fuse=fuse,
-                        static_clean=static_clean)
+                        static_clean=static_clean, forward=forward)
     hip = os.path.join(outdir, f"{cls}{suffix}.hip")
     so = os.path.join(outdir, f"lib{cls}{suffix}.so")
     flags = [opt, f"--offload-arch={arch}", "-fPIC", "-shared", "-std=c++17",
