@@ -54,13 +54,19 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
-    if os.environ.get("TC_BENCH_SINGLE_DEVICE"):   # debugging aid: several ranks on one GPU (no RCCL over xGMI then)
-        local = 0
+    single = bool(os.environ.get("TC_BENCH_SINGLE_DEVICE"))
+    if single:   # rehearsal aid: several ranks on ONE GPU. RCCL refuses two ranks on a device, so the
+        local = 0   # collectives go through gloo on host copies; never used for a reported number
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group(backend="nccl", device_id=dev)   # RCCL on ROCm; one rank per GPU
+        if single:
+            dist.init_process_group(backend="gloo")
+        else:
+            dist.init_process_group(backend="nccl", device_id=dev)   # RCCL on ROCm; one rank per GPU
+    bar = (lambda: dist.barrier()) if single else (lambda: dist.barrier(device_ids=[local]))
+    cdev = torch.device("cpu") if single else dev
 
     import __graft_entry__ as g
     from tenscalc_amd.problems.sls import SOLVE_ARGS, sls
@@ -75,7 +81,7 @@ def main():
     if rank == 0:
         so = spec.build(**kw)          # prebuilt in-tree normally; compiles here only if missing
     if world > 1:
-        dist.barrier(device_ids=[local])
+        bar()
     so = spec.build(**kw)
 
     B = args.batch
@@ -93,12 +99,15 @@ def main():
     ST = torch.as_tensor(_DevArray(sptr, (B,), "<i4"), device=dev)
     IT = torch.as_tensor(_DevArray(iptr, (B,), "<i4"), device=dev)
     from tenscalc_amd.sharding import gather_results, pack_results
-    gathered = torch.empty((world, 11, B), dtype=torch.float64, device=dev) if world > 1 else None
+    gathered = torch.empty((world, 11, B), dtype=torch.float64, device=cdev) if world > 1 else None
+
+    def exchange():   # gather results (J, x, status, iter) on every rank -- the path's only exchange
+        gather_results(pack_results(O, ST, IT).to(cdev), world, out=gathered)
 
     def step():
         obj.solve_async(SOLVE_ARGS["mu0"], SOLVE_ARGS["maxIter"], SOLVE_ARGS["addEye2Hessian"], stream=stream)
-        if world > 1:   # gather results (J, x, status, iter) on every rank -- the path's only exchange
-            gather_results(pack_results(O, ST, IT), world, out=gathered)
+        if world > 1:
+            exchange()
 
     for _ in range(args.warmup):
         step()
@@ -106,7 +115,7 @@ def main():
     kern_ms = []
     evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
     if world > 1:
-        dist.barrier(device_ids=[local])
+        bar()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for k in range(args.steps):
@@ -114,15 +123,15 @@ def main():
         obj.solve_async(SOLVE_ARGS["mu0"], SOLVE_ARGS["maxIter"], SOLVE_ARGS["addEye2Hessian"], stream=stream)
         evs[k][1].record()
         if world > 1:
-            gather_results(pack_results(O, ST, IT), world, out=gathered)
+            exchange()
     torch.cuda.synchronize()
     if world > 1:
-        dist.barrier(device_ids=[local])
+        bar()
         torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
     kern_ms = [a.elapsed_time(b_) for a, b_ in evs]          # events on the launch stream
-    el = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-    ok = (ST == 0).sum().to(torch.float64).reshape(1)
+    el = torch.tensor([elapsed], dtype=torch.float64, device=cdev)
+    ok = (ST == 0).sum().to(torch.float64).reshape(1).to(cdev)
     if world > 1:
         dist.all_reduce(el, op=dist.ReduceOp.MAX)
         dist.all_reduce(ok, op=dist.ReduceOp.SUM)
@@ -160,7 +169,7 @@ def main():
             out["cpu_baseline"] = cpu_baseline(g.sls_spec("strict"), A, b, x0, args.cpu_sample, SOLVE_ARGS)
         print(json.dumps(out), flush=True)
     if world > 1:
-        dist.barrier(device_ids=[local])
+        bar()
         dist.destroy_process_group()
     obj.close()
 

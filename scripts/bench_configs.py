@@ -57,21 +57,27 @@ res = {"metric": "IPM solves/sec, one MI355X", "value": B / t, "unit": "solves/s
 try:
     n = min(B, ncpu)
     sub = {k: v[:n] for k, v in stacked.items()}
-    if which == "quad":
+    twin = None
+    if which != "quad":
+        try:
+            from oracle.c_emitter import CpuTwin
+            twin = CpuTwin(spec)
+        except (FileNotFoundError, OSError):
+            twin = None          # not prebuilt in this checkout: time the tape interpreter instead
+    if twin is None:
         # the generated-C twin of this tape is a 44 MB source file gcc needs the better part of an hour
         # for: time the oracle's tape interpreter instead (same arithmetic, about 2x slower per instruction)
         from tenscalc_amd.tapeio import save_tape
         from oracle.tc_oracle import Oracle
-        save_tape(spec.tape, "/tmp/quad.tape")
+        save_tape(spec.tape, "/tmp/%s.tape" % which)
         c = spec.classname
-        o = Oracle("/tmp/quad.tape")
+        o = Oracle("/tmp/%s.tape" % which)
         t0 = time.perf_counter()
         out, st2, it2 = o.solve_batch({f"{c}_set_{k}": v for k, v in sub.items()}, c + "_getOutputs", n,
                                       mu0=SOLVE_ARGS["mu0"], maxIter=SOLVE_ARGS["maxIter"])
         how = "oracle tape interpreter (oracle/tc_oracle.c)"
     else:
-        from oracle.c_emitter import CpuTwin
-        tw = CpuTwin(spec)
+        tw = twin
         t0 = time.perf_counter()
         out, st2, it2 = tw.solve_batch(sub, n, mu0=SOLVE_ARGS["mu0"], maxIter=SOLVE_ARGS["maxIter"])
         how = "generated-C twin + reference ipmPD_CSsolver.c, gcc -O1"

@@ -534,6 +534,7 @@ class Printer:
         out = [self.fused_sweeps(g)]
         self._rc = {}
         self._fw_rep, self._fw_fam = {}, {}
+        self._pending = []          # slot ranges written by lane-split stores since the last wave barrier
         share = set()
         if self.recip:
             cnt = {}
@@ -556,12 +557,18 @@ class Printer:
                     nm = f"fw{u.dst0}"
                     nb = -(-u.n // L.P)
                     out.append("  double " + ", ".join(f"{nm}_{k}" for k in range(nb)) + ";\n")
+                    self._barrier_if_needed(e, out)
                     for k in range(nb):
                         import re as _re
                         ek = _re.sub(r"@FW(\w+)@", lambda m_: f"{m_.group(1)}_{k}", e)
-                        guard = "" if (k + 1) * L.P <= u.n else f"if (c_ < {u.n}) "
-                        out.append(f"  {{ const int c_ = lane + {k * L.P}; {guard}{{ {nm}_{k} = {ek}; MM({dst}) = {nm}_{k}; }} }}\n")
-                    out.append("  __builtin_amdgcn_wave_barrier();\n")
+                        if (k + 1) * L.P <= u.n:
+                            out.append(f"  {{ const int c_ = lane + {k * L.P}; {{ {nm}_{k} = {ek}; MM({dst}) = {nm}_{k}; }} }}\n")
+                        else:
+                            # ragged tail without a branch: the lanes past the end compute on whatever the
+                            # next slots hold and park the result in a spare slot nobody reads
+                            out.append(f"  {{ const int c_ = lane + {k * L.P}; {{ {nm}_{k} = {ek}; "
+                                       f"MM((c_ < {u.n}) ? ({dst}) : TC_DUMMY) = {nm}_{k}; }} }}\n")
+                    self._pending.append((u.dst0 + min(0, u.ddst * (u.n - 1)), u.dst0 + max(0, u.ddst * (u.n - 1))))
                     self._fw_fam[(u.dst0, u.ddst)] = (nm, u.n)
                 elif L.P > 1:
                     # the lanes sharing the instance split the members; LDS (in order within a
@@ -576,8 +583,12 @@ class Printer:
                 for lf in self._den_leaves(L.tree(i), []):
                     if lf.ins in share and lf.ins not in self._rc:
                         self._rc[lf.ins] = f"rc{lf.ins}"
+                        if self.forward and L.P > 1:
+                            self._barrier_if_needed(self.leaf_text(lf), out)
                         out.append(f"  const double rc{lf.ins} = TC_DIV(1.0,{self.leaf_text(lf)});\n")
             e = self.expr(L.tree(i))
+            if self.forward and L.P > 1:
+                self._barrier_if_needed(e, out)
             if L.local[i]:
                 out.append(f"  const double t{i} = {e};\n")
             elif self.forward and L.P > 1:
@@ -587,7 +598,47 @@ class Printer:
             else:
                 out.append(f"  MM({L.pslot[i]}) = {e};\n")
         self._fw_rep, self._fw_fam = {}, {}
+        if self._pending:      # later groups / entry points read through LDS
+            out.append("  __builtin_amdgcn_wave_barrier();\n")
+            self._pending = []
         return "".join(out)
+
+    # ---- lazy wave barriers (forward mode) ----------------------------------------------------
+    _MM_RE = None
+
+    def _lds_reads(self, text):
+        """slot ranges [(lo, hi)] a printed statement reads through LDS, None if it cannot be told"""
+        import re
+        if Printer._MM_RE is None:
+            Printer._MM_RE = re.compile(r"MM\(([^()]*(?:\([^()]*\)[^()]*)*)\)")
+        out = []
+        for a in Printer._MM_RE.findall(text):
+            a = a.replace(" ", "")
+            m = re.fullmatch(r"(\d+)", a)
+            if m:
+                out.append((int(m.group(1)), int(m.group(1))))
+                continue
+            m = re.fullmatch(r"(\d+)\+(?:c_|j_)", a)
+            if m:
+                out.append((int(m.group(1)), int(m.group(1)) + 63))
+                continue
+            m = re.fullmatch(r"(\d+)\+\((-?\d+)\)\*(?:c_|j_)", a)
+            if m:
+                b_, d_ = int(m.group(1)), int(m.group(2))
+                out.append((b_ + min(0, 63 * d_), b_ + max(0, 63 * d_)))
+                continue
+            return None
+        return out
+
+    def _barrier_if_needed(self, text, out):
+        """a compiler-level wave barrier is needed only before a statement that reads, through LDS, a
+        slot some OTHER lane of the instance may have written since the last barrier"""
+        if not self._pending:
+            return
+        rd = self._lds_reads(text)
+        if rd is None or any(lo <= phi and plo <= hi for lo, hi in rd for plo, phi in self._pending):
+            out.append("  __builtin_amdgcn_wave_barrier();\n")
+            self._pending = []
 
     def lane_loop(self, var, n, body):
         """members var = lane, lane+P, ... < n, fully unrolled: whole blocks of P members need no
@@ -678,10 +729,10 @@ def emit_class(spec, fp_contract="fast", block=64, stats=False, roll=True, min_w
     if interp:
         from . import interp_schedule as isch
         consts = isch.constant_rows(T, L)[0]
-    nmp = max(1, L.nPriv)
+    nmp = max(1, L.nPriv) + (2 * int(lanes) if forward and lanes > 1 else 0)   # + spare slots (TC_DUMMY, reads past a ragged tail)
     nmp += (8 - nmp) % 32
     w.append(f"#define TC_NM {max(1, L.nPriv + len(consts))}\n#define TC_NMP {nmp}\n#define TC_NEXT {L.nExt}\n#define TC_NOUT {nOut}\n"
-             f"#define TC_NGROUPS {T.nGroups}\n#define TC_NSTW {nW}\n\n")
+             f"#define TC_NGROUPS {T.nGroups}\n#define TC_NSTW {nW}\n#define TC_DUMMY {max(1, L.nPriv)}\n\n")
     dmembers = ""
     # register budget for lane-distributed inputs (doubles per lane); larger inputs stay in HBM
     budget = reg_budget
