@@ -80,6 +80,7 @@ class Printer:
         # instead of through an LDS round trip the compiler cannot remove (it does not know that the
         # other lanes of the instance write other slots)
         self.forward = False
+        self._rv = {}               # slot -> index into c.rv[]: register copy that outlives the group (setup_rcache)
         self._fw_rep = {}           # slot -> name of the register copy (replicated values)
         self._fw_fam = {}           # (first slot, slot stride) -> (name prefix of per-block copies, members)
 
@@ -320,6 +321,8 @@ class Printer:
                     b_, d_ = (base[j], delta[j]) if fam else (k.idx, 0)
                     if d_ == 0:
                         fw = self._fw_rep.get(b_)
+                        if fw is None and b_ in self._rv:
+                            fw = f"c.rv[{self._rv[b_]}]"
                     elif fam is not None and fam.var == "c_" and (b_, d_) in self._fw_fam \
                             and fam.n <= self._fw_fam[(b_, d_)][1]:
                         fw = "@FW" + self._fw_fam[(b_, d_)][0] + "@"          # per-block name, see group_body
@@ -594,6 +597,8 @@ class Printer:
             elif self.forward and L.P > 1:
                 k_ = int(L.pslot[i])
                 out.append(f"  const double r{k_}_ = {e};\n  MM({k_}) = r{k_}_;\n")
+                if k_ in self._rv:
+                    out.append(f"  c.rv[{self._rv[k_]}] = r{k_}_;\n")
                 self._fw_rep[k_] = f"r{k_}_"
             else:
                 out.append(f"  MM({L.pslot[i]}) = {e};\n")
@@ -602,6 +607,64 @@ class Printer:
             out.append("  __builtin_amdgcn_wave_barrier();\n")
             self._pending = []
         return "".join(out)
+
+    # ---- register cache of hot replicated values (lanes>1) ----------------------------------------
+    def setup_rcache(self, budget):
+        """Replicated values (every lane of the instance computes the same number) that replicated code
+        reads most often by constant index -- the pivots and factors of the sequential core of the LDL,
+        the triangular solves, scalars -- are ALSO kept in a per-lane register (c.rv[j]) next to their LDS
+        slot, so the sequential core runs without LDS round trips.  Only slots whose every writer is
+        replicated code qualify (members of lane-split families and copy destinations do not).
+        Returns the number of cached slots."""
+        L, T = self.L, self.L.T
+        if budget <= 0 or L.P == 1:
+            return 0
+        banned = set()
+        for e in list(T.copies):
+            for d in e["dst"]:
+                if L.pslot[d] >= 0:
+                    banned.add(int(L.pslot[d]))
+        writer_ok = {}
+        cnt = {}
+
+        def visit(t, fam):
+            for k in t.kids:
+                if isinstance(k, Leaf):
+                    if k.kind == "priv":
+                        cnt[k.idx] = cnt.get(k.idx, 0) + 1      # refined below for family operands
+                else:
+                    visit(k, fam)
+        for g in range(1, T.nGroups + 1):
+            for u in L.units[g - 1]:
+                if isinstance(u, Family):
+                    # operands with stride 0 are broadcast reads of a constant slot
+                    pos = 0
+                    def walk(t):
+                        nonlocal pos
+                        for k in t.kids:
+                            if isinstance(k, Leaf):
+                                if k.kind == "priv" and u.delta[pos] == 0:
+                                    cnt[u.base[pos]] = cnt.get(u.base[pos], 0) + 1
+                                pos += 1
+                            else:
+                                walk(k)
+                    walk(u.template)
+                    for i in u.members:
+                        banned.add(int(L.pslot[i]))
+                elif isinstance(u, (int, np.integer)):
+                    i = int(u)
+                    visit(L.tree(i), None)
+                    if not L.local[i] and L.pslot[i] >= 0:
+                        writer_ok[int(L.pslot[i])] = True
+        for e in T.sets:
+            if not e["external"]:
+                for i in e["ins"]:
+                    if L.pslot[i] >= 0:
+                        writer_ok[int(L.pslot[i])] = True
+        cand = sorted((k for k in cnt if writer_ok.get(k) and k not in banned), key=lambda k: (-cnt[k], k))
+        cand = [k for k in cand if cnt[k] >= 2][:int(budget)]
+        self._rv = {k: j for j, k in enumerate(cand)}
+        return len(cand)
 
     # ---- lazy wave barriers (forward mode) ----------------------------------------------------
     _MM_RE = None
@@ -671,7 +734,7 @@ def _mask(groups):
 
 def emit_class(spec, fp_contract="fast", block=64, stats=False, roll=True, min_waves=0, lanes=1,
                recip=False, fast_div=False, inline_max=0, reg_budget=150, scratch="auto", body="code",
-               waves=1, fuse=False, static_clean=False, forward=False):
+               waves=1, fuse=False, static_clean=False, forward=False, rcache=0):
     """Return the HIP source text of the solver class.
 
     static_clean=True: tests and code of dependency groups that are certainly clean at an entry
@@ -703,6 +766,9 @@ def emit_class(spec, fp_contract="fast", block=64, stats=False, roll=True, min_w
         raise ValueError("block must be a multiple of lanes")
     P = Printer(L, roll=roll, recip=recip, fuse=fuse)
     P.forward = bool(forward) and lanes > 1
+    nrv = P.setup_rcache(rcache) if (P.forward and not interp) else 0
+    if nrv:
+        inline_max = 10 ** 9        # the register copies live in the kernel's context: every group inlined
     cls = spec.classname
     nW = max(1, (T.nGroups + 63) // 64)
     w = []
@@ -768,7 +834,7 @@ def emit_class(spec, fp_contract="fast", block=64, stats=False, roll=True, min_w
              "typedef __attribute__((address_space(1))) double *tc_gmem;\n"
              f"typedef {mem_t} tc_mem;\n#define TC_SCRATCH_{scratch.upper()} 1\n"
              "struct TcCtx {\n  tc_mem m;\n  tc_glob S;\n  tc_glob Sd;\n  long B, sdB;\n  int lane;\n"
-             "  unsigned long long st[TC_NSTW];\n" + dmembers +
+             "  unsigned long long st[TC_NSTW];\n" + (f"  double rv[{nrv}];\n" if nrv else "") + dmembers +
              "#ifdef TC_STATS\n  int nMinF;\n  long long cyc[TC_NGROUPS];\n  int cnt[TC_NGROUPS];\n#endif\n};\n"
              f"#define SX(k) (S[(long)(k) * B])\n#define MM(k) {mm}\n"
              "#define TC_UNPACK tc_mem m = c.m; tc_glob S = c.S; const long B = c.B; const int lane = c.lane; (void)m; (void)S; (void)B; (void)lane;\n"
@@ -883,6 +949,8 @@ def emit_class(spec, fp_contract="fast", block=64, stats=False, roll=True, min_w
         for k, i in enumerate(e["ins"]):
             if L.pslot[i] >= 0:
                 w.append(f"  MM({L.pslot[i]}) = input[{k}];\n")
+                if int(L.pslot[i]) in P._rv:
+                    w.append(f"  c.rv[{P._rv[int(L.pslot[i])]}] = input[{k}];\n")
         w.append(inval(e["children"]))
         w.append("}\n")
     elide, sure = {}, {}
@@ -1127,7 +1195,7 @@ def class_header(spec):
 def build_class(spec, fp_contract="fast", arch="gfx950", opt="-O3", block=64, force=False,
                 outdir=None, stats=False, tag=None, extra_flags=(), roll=True, min_waves=0, lanes=1,
                 recip=False, fast_div=False, inline_max=0, reg_budget=150, scratch="auto", body="code",
-                waves=1, fuse=False, static_clean=False, forward=False):
+                waves=1, fuse=False, static_clean=False, forward=False, rcache=0):
     """Emit <cls>.hip (+ <cls>.h, <cls>.tape) and compile lib<cls>.so with hipcc for gfx950.
     Mirrors the createGateway/compile step of cmex2optimizeCS.m:403-417."""
     from .tapeio import save_tape
@@ -1138,7 +1206,7 @@ def build_class(spec, fp_contract="fast", arch="gfx950", opt="-O3", block=64, fo
     src, L = emit_class(spec, fp_contract=fp_contract, block=block, stats=stats, roll=roll,
                         min_waves=min_waves, lanes=lanes, recip=recip, fast_div=fast_div, inline_max=inline_max,
                         reg_budget=reg_budget, scratch=scratch, body=body, waves=waves, fuse=fuse,
-                        static_clean=static_clean, forward=forward)
+                        static_clean=static_clean, forward=forward, rcache=rcache)
     hip = os.path.join(outdir, f"{cls}{suffix}.hip")
     so = os.path.join(outdir, f"lib{cls}{suffix}.so")
     flags = [opt, f"--offload-arch={arch}", "-fPIC", "-shared", "-std=c++17",
