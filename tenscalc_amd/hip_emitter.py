@@ -734,8 +734,13 @@ def _mask(groups):
 
 def emit_class(spec, fp_contract="fast", block=64, stats=False, roll=True, min_waves=0, lanes=1,
                recip=False, fast_div=False, inline_max=0, reg_budget=150, scratch="auto", body="code",
-               waves=1, fuse=False, static_clean=False, forward=False, rcache=0):
+               waves=1, fuse=False, static_clean=False, forward=False, rcache=0, lds_state=0):
     """Return the HIP source text of the solver class.
+
+    lds_state=N (register-resident lowering only: lanes=1, roll=False): up to N long-lived state values
+    per instance -- what depends on the parameters only and what is carried from one Newton iteration to
+    the next -- live in LDS ([slot][thread], conflict-free) instead of competing with the transient values
+    of an iteration for the 512 registers; N*8*block bytes of LDS per block set the occupancy.
 
     static_clean=True: tests and code of dependency groups that are certainly clean at an entry
     point's call sites in the Newton loop are left out there (loop_schedule.py); unelided twins
@@ -833,10 +838,10 @@ def emit_class(spec, fp_contract="fast", block=64, stats=False, roll=True, min_w
              "typedef const __attribute__((address_space(1))) double *tc_glob;\n"
              "typedef __attribute__((address_space(1))) double *tc_gmem;\n"
              f"typedef {mem_t} tc_mem;\n#define TC_SCRATCH_{scratch.upper()} 1\n"
-             "struct TcCtx {\n  tc_mem m;\n  tc_glob S;\n  tc_glob Sd;\n  long B, sdB;\n  int lane;\n"
+             "struct TcCtx {\n  tc_mem m;\n  tc_lds ls;\n  tc_glob S;\n  tc_glob Sd;\n  long B, sdB;\n  int lane;\n"
              "  unsigned long long st[TC_NSTW];\n" + (f"  double rv[{nrv}];\n" if nrv else "") + dmembers +
              "#ifdef TC_STATS\n  int nMinF;\n  long long cyc[TC_NGROUPS];\n  int cnt[TC_NGROUPS];\n#endif\n};\n"
-             f"#define SX(k) (S[(long)(k) * B])\n#define MM(k) {mm}\n"
+             f"#define SX(k) (S[(long)(k) * B])\n#define MM(k) {mm}\n#define ML(j) (c.ls[(j) * TC_BLOCK])\n"
              "#define TC_UNPACK tc_mem m = c.m; tc_glob S = c.S; const long B = c.B; const int lane = c.lane; (void)m; (void)S; (void)B; (void)lane;\n"
              "#define TC_NUM(x, d) (x)\n"
              + ("// opt-in fast division: hardware reciprocal + two Newton steps + one residual correction\n"
@@ -1036,6 +1041,7 @@ def emit_class(spec, fp_contract="fast", block=64, stats=False, roll=True, min_w
                 "  TcCtx c;\n"
                 "#if defined(TC_SCRATCH_GLOBAL)\n  c.m = (tc_gmem)(Mg + ((tid >> 6) * (long)(TC_NEXT + TC_NM) + TC_NEXT) * 64 + (tid & 63));\n"
                 "#elif TC_P == 1\n  double mm_[TC_NM];\n  c.m = (tc_priv)mm_;\n"
+                "#ifdef TC_NLS\n  __shared__ double tc_lds_s[TC_NLS * TC_BLOCK];\n  c.ls = (tc_lds)&tc_lds_s[threadIdx.x];\n#endif\n"
                 "#else\n  __shared__ double tc_lds_m[TC_NMP * TC_G];\n  c.m = (tc_lds)&tc_lds_m[(threadIdx.x / TC_P) * TC_NMP];\n#endif\n"
                 "  c.lane = (int)(t_ % TC_P);\n  c.S = (tc_glob)(S + tid);\n  c.B = B;\n"
                 "  for (int k = 0; k < TC_NSTW; k++) c.st[k] = 0;\n"
@@ -1110,8 +1116,37 @@ def emit_class(spec, fp_contract="fast", block=64, stats=False, roll=True, min_w
             po += n_
         w.append("    } break;\n")
     w.append("    default: break;\n  }\n}\n\n")
+    if lds_state and lanes == 1 and not roll and not interp:
+        w = [_place_state_in_lds("".join(w), T, L, spec, int(lds_state))]
     w.append(_class_tail(spec, T, L, out_meta, probes, lanes, nOut))
     return "".join(w), L
+
+
+def _place_state_in_lds(src, T, L, spec, budget):
+    """register-resident lowering: move the long-lived slots to LDS (textual: every state access of this
+    lowering is MM(<constant>))"""
+    import re
+    from .loop_schedule import analyse
+    analyse(T, spec.defines)
+    transient = set(analyse.loop_head_dirty)
+    longlived = set()
+    for i in range(1, T.n + 1):
+        k = int(L.pslot[i])
+        if k < 0:
+            continue
+        g_ = int(T.group[i])
+        if g_ == 0 or g_ not in transient:
+            longlived.add(k)             # set / copy destinations and parameter-only groups
+    if re.search(r"MM\((?!\d+\))", src.split("#define MM(k)")[1].split("\n", 1)[1]):
+        raise AssertionError("lds_state needs constant state indices everywhere (roll=False)")
+    refs = {}
+    for m_ in re.finditer(r"MM\((\d+)\)", src):
+        refs[int(m_.group(1))] = refs.get(int(m_.group(1)), 0) + 1
+    cand = sorted((k for k in longlived if refs.get(k, 0) > 0), key=lambda k: (refs[k], k))[:budget]
+    where = {k: j for j, k in enumerate(cand)}
+    head, body = src.split("#define MM(k)", 1)
+    body = re.sub(r"MM\((\d+)\)", lambda m_: f"ML({where[int(m_.group(1))]})" if int(m_.group(1)) in where else m_.group(0), body)
+    return head + f"#define TC_NLS {max(1, len(cand))}\n#define MM(k)" + body
 
 
 def _class_tail(spec, T, L, out_meta, probes, lanes, nOut):
@@ -1195,7 +1230,7 @@ def class_header(spec):
 def build_class(spec, fp_contract="fast", arch="gfx950", opt="-O3", block=64, force=False,
                 outdir=None, stats=False, tag=None, extra_flags=(), roll=True, min_waves=0, lanes=1,
                 recip=False, fast_div=False, inline_max=0, reg_budget=150, scratch="auto", body="code",
-                waves=1, fuse=False, static_clean=False, forward=False, rcache=0):
+                waves=1, fuse=False, static_clean=False, forward=False, rcache=0, lds_state=0):
     """Emit <cls>.hip (+ <cls>.h, <cls>.tape) and compile lib<cls>.so with hipcc for gfx950.
     Mirrors the createGateway/compile step of cmex2optimizeCS.m:403-417."""
     from .tapeio import save_tape
@@ -1206,7 +1241,7 @@ def build_class(spec, fp_contract="fast", arch="gfx950", opt="-O3", block=64, fo
     src, L = emit_class(spec, fp_contract=fp_contract, block=block, stats=stats, roll=roll,
                         min_waves=min_waves, lanes=lanes, recip=recip, fast_div=fast_div, inline_max=inline_max,
                         reg_budget=reg_budget, scratch=scratch, body=body, waves=waves, fuse=fuse,
-                        static_clean=static_clean, forward=forward, rcache=rcache)
+                        static_clean=static_clean, forward=forward, rcache=rcache, lds_state=lds_state)
     hip = os.path.join(outdir, f"{cls}{suffix}.hip")
     so = os.path.join(outdir, f"lib{cls}{suffix}.so")
     flags = [opt, f"--offload-arch={arch}", "-fPIC", "-shared", "-std=c++17",
