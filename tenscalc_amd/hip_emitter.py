@@ -1261,6 +1261,8 @@ def build_class(spec, fp_contract="fast", arch="gfx950", opt="-O3", block=64, fo
         f.write(src)
     with open(os.path.join(outdir, f"{cls}.h"), "w") as f:
         f.write(class_header(spec))
+    from .matlab_class import write_matlab_class
+    write_matlab_class(spec, libname=os.path.basename(so), outdir=outdir)     # @<cls>/<cls>.m
     save_tape(spec.tape, os.path.join(outdir, f"{cls}.tape"))
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
     cmd = [hipcc] + flags + [hip, "-o", so]
