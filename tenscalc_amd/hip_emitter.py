@@ -1129,14 +1129,25 @@ def _place_state_in_lds(src, T, L, spec, budget):
     from .loop_schedule import analyse
     analyse(T, spec.defines)
     transient = set(analyse.loop_head_dirty)
+    # who reads each value inside the loop: instructions of transient groups, loop entry points directly
+    read_in_loop = set()
+    for i in range(1, T.n + 1):
+        if T.used[i] and int(T.group[i]) in transient:
+            for j in L.operands(i):
+                read_in_loop.add(int(j))
+    for e in list(T.gets) + list(T.copies):
+        if e["name"].endswith("_getOutputs") or e["name"] in ("getGrad__", "getJ__", "getHessInertia__"):
+            continue
+        for j in list(e.get("src", [])) + [x for o in e.get("outputs", []) for x in o["ins"]]:
+            read_in_loop.add(int(j))
     longlived = set()
     for i in range(1, T.n + 1):
         k = int(L.pslot[i])
         if k < 0:
             continue
         g_ = int(T.group[i])
-        if g_ == 0 or g_ not in transient:
-            longlived.add(k)             # set / copy destinations and parameter-only groups
+        if (g_ == 0 or g_ not in transient) and i in read_in_loop:
+            longlived.add(k)             # carried between iterations, or parameter-only and used every iteration
     if re.search(r"MM\((?!\d+\))", src.split("#define MM(k)")[1].split("\n", 1)[1]):
         raise AssertionError("lds_state needs constant state indices everywhere (roll=False)")
     refs = {}
