@@ -21,9 +21,20 @@ struct TcCtx {
   tco_t *g;
 };
 
-#define COPY(fn) static inline void fn(TcCtx &c) { tco_copy(c.g, tco_entry(c.g, #fn)); }
-#define SET(fn) static inline void fn(TcCtx &c, const double *x) { tco_set(c.g, tco_entry(c.g, #fn), x); }
-#define GET1(fn) static inline void fn(TcCtx &c, double *x) { tco_get_flat(c.g, tco_entry(c.g, #fn), x); }
+/* trace of entry-point calls (entry indices) of the last tcdev_solve: tests/test_loop_schedule.py replays
+ * it against the static clean/dirty claims of tenscalc_amd/loop_schedule.py */
+#define TC_TRACE_MAX (1 << 20)
+static int g_trace[TC_TRACE_MAX];
+static int g_ntrace;
+static inline int traced(tco_t *g, const char *name) {
+  const int e = tco_entry(g, name);
+  if (g_ntrace < TC_TRACE_MAX) g_trace[g_ntrace++] = e;
+  return e;
+}
+
+#define COPY(fn) static inline void fn(TcCtx &c) { tco_copy(c.g, traced(c.g, #fn)); }
+#define SET(fn) static inline void fn(TcCtx &c, const double *x) { tco_set(c.g, traced(c.g, #fn), x); }
+#define GET1(fn) static inline void fn(TcCtx &c, double *x) { tco_get_flat(c.g, traced(c.g, #fn), x); }
 
 COPY(initPrimal__)
 COPY(initDualEqX__)
@@ -45,20 +56,20 @@ GET1(getCurvature__)
 GET1(getMinF_s__)
 static inline void getGapMinFMinLambda__(TcCtx &c, double *gap, double *ineq, double *dual) {
   double t[3];
-  tco_get_flat(c.g, tco_entry(c.g, "getGapMinFMinLambda__"), t);
+  tco_get_flat(c.g, traced(c.g, "getGapMinFMinLambda__"), t);
   *gap = t[0];
   *ineq = t[1];
   *dual = t[2];
 }
 static inline void getMaxAlphas_s__(TcCtx &c, double *alphaPrimal, double *alphaDual) {
   double t[2];
-  tco_get_flat(c.g, tco_entry(c.g, "getMaxAlphas_s__"), t);
+  tco_get_flat(c.g, traced(c.g, "getMaxAlphas_s__"), t);
   *alphaPrimal = t[0];
   *alphaDual = t[1];
 }
 static inline void getHessInertia__(TcCtx &c, double *mp, double *mn) {
   double t[2];
-  tco_get_flat(c.g, tco_entry(c.g, "getHessInertia__"), t);
+  tco_get_flat(c.g, traced(c.g, "getHessInertia__"), t);
   *mp = t[0];
   *mn = t[1];
 }
@@ -70,7 +81,14 @@ extern "C" void tcdev_solve(tco_t *g, double mu0, int maxIter, double ae0, doubl
                             int32_t *iter) {
   TcCtx c = {g};
   int st = 0, it = 0;
+  g_ntrace = 0;
   ipmPD_CSsolver(c, mu0, maxIter, ae0, ae1, &st, &it);
   *status = st;
   *iter = it;
+}
+
+extern "C" int tcdev_trace(int32_t *out, int max) {
+  const int n = g_ntrace < max ? g_ntrace : max;
+  for (int k = 0; k < n; k++) out[k] = g_trace[k];
+  return g_ntrace;
 }

@@ -145,3 +145,12 @@ class DeviceLoopOracle(Oracle):
         self.L.tcdev_solve(self.h, float(mu0), int(maxIter), float(addEye2Hessian[0]),
                            float(addEye2Hessian[1]), ctypes.byref(st), ctypes.byref(it))
         return st.value, it.value
+
+    def trace(self):
+        """names of the entry points the last solve() called, in order"""
+        self.L.tcdev_trace.argtypes = [_i32p, ctypes.c_int]
+        self.L.tco_entry_name.restype = ctypes.c_char_p
+        self.L.tco_entry_name.argtypes = [ctypes.c_void_p, ctypes.c_int]
+        buf = np.zeros(1 << 20, dtype=np.int32)
+        n = self.L.tcdev_trace(buf.ctypes.data_as(_i32p), buf.size)
+        return [self.L.tco_entry_name(self.h, int(e)).decode() for e in buf[:min(n, buf.size)]]
