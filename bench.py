@@ -39,7 +39,7 @@ def main():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--batch", type=int, default=65536, help="instances per GPU")
-    ap.add_argument("--variant", default=os.environ.get("TC_BENCH_VARIANT", "w8"), choices=["strict", "fast", "w8", "w8h", "regs", "regsl"],
+    ap.add_argument("--variant", default=os.environ.get("TC_BENCH_VARIANT", "w8"), choices=["strict", "fast", "w8", "w8h", "regs", "regsl", "w8s"],
                     help="strict: 1 thread/instance, -ffp-contract=off, bit-exact vs the oracle; fast: same with FMA; "
                          "w8: 8 lanes/instance wave-cooperative lowering (default); w8h / regs: the hoisted tape "
                          "(parameter-only contractions first) under w8 / the register-resident lowering")

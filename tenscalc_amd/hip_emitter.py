@@ -74,6 +74,7 @@ class Printer:
         self._rc = {}               # denominator instruction id -> name of its reciprocal in this group
         self.fuse = fuse            # long sums over the inputs share ONE sweep (see fused_sweeps)
         self._fused = {}            # sum instruction id -> name of its accumulated value in this group
+        self._fused_d = {}          # distributed reduction id -> (name of its per-lane partial sum, scale)
         # store->load forwarding inside a group (lanes>1): a value just written to LDS by this lane is
         # read back from the register that holds it -- a replicated value by every later statement of
         # the group, element c_ of a lane-split family by the aligned member c_ of a later family --
@@ -117,12 +118,17 @@ class Printer:
             if not d.get("resident", True):
                 # too large to keep in registers: read this lane's element from the distributed
                 # block on every use (still one 512-byte line per wave-load)
-                return f"c.Sd[(long)({d['off'] + vec[2] * d['K'] + k}) * c.sdB]"
+                # uniform base + 32-bit byte offset (global_load with scalar base): a 64-bit per-lane address
+                # for each of the ~120 elements would otherwise sit in registers for the whole kernel
+                if isinstance(k, str):          # rolled sweep: row block index is a loop variable
+                    return f"TC_SD({d['off'] + vec[2] * d['K']} + {k})"
+                return f"TC_SD({d['off'] + vec[2] * d['K'] + k})"
             return f"c.dX{vec[1]}[{vec[2] * d['K'] + k}]"
         return f"c.dF{vec[1]}[{k}]"
 
-    def reduction(self, t):
-        """sum over aligned distributed operands: per-lane partial sum + butterfly all-reduce"""
+    def _reduction_terms(self, t, symbolic=False):
+        """per-lane terms (one per block of P rows) of a sum over aligned distributed operands, and the
+        power-of-two literal factor taken out of the sum"""
         L = self.L
         nf, ns, facs = L.dreduce[t.ins]
         P_ = L.P
@@ -140,7 +146,7 @@ class Printer:
         if len(skip) == len(facs):
             skip, scale = set(), 1.0
         terms = []
-        for k in range(K):
+        for k in list(range(K)) + (["k_"] if symbolic else []):
             fs = []
             for p, (kind, v) in enumerate(facs):
                 if p in skip:
@@ -150,13 +156,84 @@ class Printer:
                 else:
                     fs.append(self.leaf_text(t.kids[p]))
             tk = f"{fs[0]}*{fs[0]}" if t.typ == I.I_plus_sqr else "*".join(fs)
-            if (k + 1) * P_ > ns:
+            if not isinstance(k, str) and (k + 1) * P_ > ns:
                 tk = f"(({k * P_}+c.lane<{ns})?({tk}):0.0)"
             terms.append(tk)
+        if symbolic:
+            return terms[:-1], scale, terms[-1]
+        return terms, scale
+
+    def reduction(self, t):
+        """sum over aligned distributed operands: per-lane partial sum + butterfly all-reduce"""
+        if t.ins in self._fused_d:
+            e, scale = self._fused_d[t.ins]
+            return f"tc_allreduce({e})" if scale == 1.0 else f"({_lit(scale)}*tc_allreduce({e}))"
+        terms, scale = self._reduction_terms(t)
         e = terms[0]
         for tk in terms[1:]:
             e = f"({e})+{tk}"
         return f"tc_allreduce({e})" if scale == 1.0 else f"({_lit(scale)}*tc_allreduce({e}))"
+
+    def _dreduce_nodes(self, t, acc):
+        if isinstance(t, Leaf):
+            return acc
+        if t.ins in self.L.dreduce:
+            acc.append(t)
+            return acc
+        for k in t.kids:
+            self._dreduce_nodes(k, acc)
+        return acc
+
+    def fused_dsweeps(self, g):
+        """lanes>1, distributed inputs NOT resident in registers (reg_budget=0: the hoisted tape needs them
+        only before and after the Newton loop): all reductions of the group over those inputs (36+8 for
+        hoisted sls) accumulate in ONE sweep over the row blocks, so a row block is loaded once (9 loads,
+        44 multiply-adds) instead of being held in ~230 registers by 44 separate expressions.  Per-lane
+        term order is unchanged."""
+        L = self.L
+        self._fused_d = {}
+        if L.P == 1 or not self.fuse:
+            return ""
+        nodes = []
+        for u in L.units[g - 1]:
+            if isinstance(u, (int, np.integer)):
+                self._dreduce_nodes(L.tree(int(u)), nodes)
+
+        def streamed(t):
+            return all(kind != "d" or (v[0] == "X" and not [x for x in L.inputs if x["dist"] and x["arr"] == v[1]][0].get("resident", True))
+                       for kind, v in L.dreduce[t.ins][2])
+        nodes = [t for t in nodes if streamed(t)]
+        if len(nodes) < 2:
+            return ""
+        per = [self._reduction_terms(t, symbolic=True) for t in nodes]
+        K = max(len(terms) for terms, _, _ in per)
+        if any(len(terms) != K for terms, _, _ in per):
+            return ""
+        import re
+        ref_re = re.compile(r"TC_SD\([^()]*\)")
+
+        def block(texts, tag):
+            """one row block: every distinct input element is loaded once into a local"""
+            loads, lines = {}, []
+            for t, tk in zip(nodes, texts):
+                for ref in sorted(set(ref_re.findall(tk))):
+                    nm = loads.setdefault(ref, f"ld{tag}_{len(loads)}")
+                    tk = tk.replace(ref, nm)
+                lines.append(f"    fd{t.ins} = (fd{t.ins})+{tk};\n")
+            return "".join(f"    const double {nm} = {ref};\n" for ref, nm in loads.items()) + "".join(lines)
+        ragged = any("c.lane<" in terms[-1] for terms, _, _ in per)
+        nroll = K - 1 if ragged else K
+        w = "  double " + ", ".join(f"fd{t.ins} = 0.0" for t in nodes) + ";\n"
+        # a real loop (not unrolled): otherwise the scheduler hoists every load of the sweep to the top and
+        # holds all of the inputs in registers again
+        un = os.environ.get("TC_SWEEP_UNROLL", "4")     # row blocks in flight per trip (loads overlap inside a trip)
+        w += f"  _Pragma(\"unroll {un}\") for (int k_ = 0; k_ < {nroll}; k_++) {{\n" + block([sym for _, _, sym in per], "") + "  }\n"
+        if ragged:
+            w += "  {\n" + block([terms[-1] for terms, _, _ in per], "t") + "  }\n"
+        per = [(terms, scale) for terms, scale, _ in per]
+        for t, (terms, scale) in zip(nodes, per):
+            self._fused_d[t.ins] = (f"fd{t.ins}", scale)
+        return w
 
     def dfamily_body(self, f):
         L = self.L
@@ -534,7 +611,7 @@ class Printer:
     def group_body(self, g):
         """HIP statements of dependency group g (1-based)"""
         L = self.L
-        out = [self.fused_sweeps(g)]
+        out = [self.fused_sweeps(g), self.fused_dsweeps(g)]
         self._rc = {}
         self._fw_rep, self._fw_fam = {}, {}
         self._pending = []          # slot ranges written by lane-split stores since the last wave barrier
@@ -734,8 +811,11 @@ def _mask(groups):
 
 def emit_class(spec, fp_contract="fast", block=64, stats=False, roll=True, min_waves=0, lanes=1,
                recip=False, fast_div=False, inline_max=0, reg_budget=150, scratch="auto", body="code",
-               waves=1, fuse=False, static_clean=False, forward=False, rcache=0, lds_state=0):
+               waves=1, fuse=False, static_clean=False, forward=False, rcache=0, lds_state=0, share=False):
     """Return the HIP source text of the solver class.
+
+    share=True: values of transient groups with disjoint life times inside a pass of the Newton loop share
+    storage (Lowering._assign_shared_slots); such classes do not support tc_probe.
 
     lds_state=N (register-resident lowering only: lanes=1, roll=False): up to N long-lived state values
     per instance -- what depends on the parameters only and what is carried from one Newton iteration to
@@ -766,7 +846,8 @@ def emit_class(spec, fp_contract="fast", block=64, stats=False, roll=True, min_w
         block = 64 * int(waves)
         L = Lowering(T, None, roll=False, lanes=1, spill_all=True)
     else:
-        L = Lowering(T, getattr(spec, "code", None), roll=roll, lanes=lanes)
+        L = Lowering(T, getattr(spec, "code", None), roll=roll, lanes=lanes,
+                     share=spec.defines if share else None)
     if block % lanes:
         raise ValueError("block must be a multiple of lanes")
     P = Printer(L, roll=roll, recip=recip, fuse=fuse)
@@ -800,8 +881,12 @@ def emit_class(spec, fp_contract="fast", block=64, stats=False, roll=True, min_w
     if interp:
         from . import interp_schedule as isch
         consts = isch.constant_rows(T, L)[0]
-    nmp = max(1, L.nPriv) + (2 * int(lanes) if forward and lanes > 1 else 0)   # + spare slots (TC_DUMMY, reads past a ragged tail)
-    nmp += (8 - nmp) % 32
+    nmp = max(1, L.nPriv) + (1 if forward and lanes > 1 else 0)   # + TC_DUMMY
+    nmp += int(os.environ.get("TC_LDS_PAD_SLOTS", "0"))      # occupancy experiments only
+    # per-instance stride = 8 mod 16 doubles: the 4 instances of a half-wave start 16 banks apart either way
+    # (8 mod 32: 0,16,32,48; 24 mod 32: 0,48,32,16), so broadcast reads and 8-lane reads of consecutive
+    # slots are conflict-free
+    nmp += (8 - nmp) % 16
     w.append(f"#define TC_NM {max(1, L.nPriv + len(consts))}\n#define TC_NMP {nmp}\n#define TC_NEXT {L.nExt}\n#define TC_NOUT {nOut}\n"
              f"#define TC_NGROUPS {T.nGroups}\n#define TC_NSTW {nW}\n#define TC_DUMMY {max(1, L.nPriv)}\n\n")
     dmembers = ""
@@ -814,6 +899,8 @@ def emit_class(spec, fp_contract="fast", block=64, stats=False, roll=True, min_w
     for d in L.inputs:
         if d["dist"] and d["resident"]:
             dmembers += f"  double dX{d['arr']}[{d['rest'] * d['K']}];\n"
+    if any(d["dist"] and not d["resident"] for d in L.inputs):
+        w.append("#define TC_SD32 1\n")
     for f in L.dfamilies.values():
         dmembers += f"  double dF{f.fid}[{-(-f.n // L.P)}];\n"
     # where values that cross group boundaries live: per-thread private memory (lanes=1), LDS shared by
@@ -839,9 +926,13 @@ def emit_class(spec, fp_contract="fast", block=64, stats=False, roll=True, min_w
              "typedef __attribute__((address_space(1))) double *tc_gmem;\n"
              f"typedef {mem_t} tc_mem;\n#define TC_SCRATCH_{scratch.upper()} 1\n"
              "struct TcCtx {\n  tc_mem m;\n  tc_lds ls;\n  tc_glob S;\n  tc_glob Sd;\n  long B, sdB;\n  int lane;\n"
+             "  const __attribute__((address_space(1))) char *Sdb;\n  unsigned sdo8, sdB8;\n"
              "  unsigned long long st[TC_NSTW];\n" + (f"  double rv[{nrv}];\n" if nrv else "") + dmembers +
              "#ifdef TC_STATS\n  int nMinF;\n  long long cyc[TC_NGROUPS];\n  int cnt[TC_NGROUPS];\n#endif\n};\n"
              f"#define SX(k) (S[(long)(k) * B])\n#define MM(k) {mm}\n#define ML(j) (c.ls[(j) * TC_BLOCK])\n"
+             "// element j of this lane's share of a distributed input that is not resident in registers;\n"
+             "// 32-bit byte offsets: the host refuses batches whose distributed block reaches 4 GiB (TC_SD32)\n"
+             "#define TC_SD(j) (*(tc_glob)(c.Sdb + (unsigned)((unsigned)(j) * c.sdB8 + c.sdo8)))\n"
              "#define TC_UNPACK tc_mem m = c.m; tc_glob S = c.S; const long B = c.B; const int lane = c.lane; (void)m; (void)S; (void)B; (void)lane;\n"
              "#define TC_NUM(x, d) (x)\n"
              + ("// opt-in fast division: hardware reciprocal + two Newton steps + one residual correction\n"
@@ -906,6 +997,25 @@ def emit_class(spec, fp_contract="fast", block=64, stats=False, roll=True, min_w
     # PUSHED, not pulled: the set/copy that invalidates such a group re-evaluates it on the spot
     # (after its ancestors), so every get/copy can assume it is clean and never tests it.
     Dg = [g for g in range(1, T.nGroups + 1) if P.group_uses_distributed(g)]
+    if static_clean and not interp:
+        # ... except distributed groups that only getOutputs (or a get the loop never calls) needs: pushing
+        # them would re-evaluate them -- for inputs not resident in registers: re-read the inputs from
+        # HBM -- on every primal update although they are read once, after the loop; they are pulled there
+        from .loop_schedule import newton_program
+
+        def _names(nodes, acc):
+            for nd in nodes:
+                if nd[0] == "call":
+                    acc.add(nd[1])
+                elif nd[0] in ("if", "loop"):
+                    _names(nd[1], acc)
+            return acc
+        called = _names(newton_program(spec.defines), set())
+        in_loop = set()
+        for e in list(T.gets) + list(T.copies):
+            if e["name"] in called:
+                in_loop |= set(e["parents"])
+        Dg = [g for g in Dg if g in in_loop]
     gdeps = {g: set() for g in range(1, T.nGroups + 1)}
     for g, members in enumerate(T.groups, 1):
         for i in members:
@@ -1042,12 +1152,15 @@ def emit_class(spec, fp_contract="fast", block=64, stats=False, roll=True, min_w
                 "#if defined(TC_SCRATCH_GLOBAL)\n  c.m = (tc_gmem)(Mg + ((tid >> 6) * (long)(TC_NEXT + TC_NM) + TC_NEXT) * 64 + (tid & 63));\n"
                 "#elif TC_P == 1\n  double mm_[TC_NM];\n  c.m = (tc_priv)mm_;\n"
                 "#ifdef TC_NLS\n  __shared__ double tc_lds_s[TC_NLS * TC_BLOCK];\n  c.ls = (tc_lds)&tc_lds_s[threadIdx.x];\n#endif\n"
-                "#else\n  __shared__ double tc_lds_m[TC_NMP * TC_G];\n  c.m = (tc_lds)&tc_lds_m[(threadIdx.x / TC_P) * TC_NMP];\n#endif\n"
+                "#else\n  __shared__ double tc_lds_m[TC_NMP * TC_G + 8];   // + 8: reads past a ragged family tail of the last instance\n"
+                "  c.m = (tc_lds)&tc_lds_m[(threadIdx.x / TC_P) * TC_NMP];\n#endif\n"
                 "  c.lane = (int)(t_ % TC_P);\n  c.S = (tc_glob)(S + tid);\n  c.B = B;\n"
                 "  for (int k = 0; k < TC_NSTW; k++) c.st[k] = 0;\n"
                 "#ifdef TC_STATS\n  c.nMinF = 0;\n  for (int k = 0; k < TC_NGROUPS; k++) { c.cyc[k] = 0; c.cnt[k] = 0; }\n"
                 "  const long long tstart_ = clock64();\n#endif\n")
-    prologue += "  c.Sd = (tc_glob)(Sd + tid * TC_P + c.lane);\n  c.sdB = B * TC_P;\n"
+    prologue += ("  c.Sd = (tc_glob)(Sd + tid * TC_P + c.lane);\n  c.sdB = B * TC_P;\n"
+                 "  c.Sdb = (const __attribute__((address_space(1))) char *)Sd;\n"
+                 "  c.sdo8 = (unsigned)((tid * TC_P + c.lane) * 8);\n  c.sdB8 = (unsigned)(B * TC_P * 8);\n")
     if interp:
         prologue += ("  for (int k = 0; k < TC_NCONST; k++) c.m[(long)(TC_NPRIV + k) * 64] = tc_consts[k];\n"
                      "  for (int k = 0; k < TC_NEXT; k++) c.m[(long)(k - TC_NEXT) * 64] = S[(long)k * B + tid];\n")
@@ -1102,7 +1215,7 @@ def emit_class(spec, fp_contract="fast", block=64, stats=False, roll=True, min_w
              f"#if nG > 0\n  initDualEqX__{full}(c);\n#endif\n"
              "  switch (which) {\n")
     probes = []
-    for k, e in enumerate(T.gets):
+    for k, e in enumerate(T.gets if not share else []):     # shared storage has no schedule for a lone get
         tot = sum(len(o["ins"]) for o in e["outputs"])
         probes.append((e["name"], tot))
         w.append(f"    case {k}: {{\n")
@@ -1241,7 +1354,7 @@ def class_header(spec):
 def build_class(spec, fp_contract="fast", arch="gfx950", opt="-O3", block=64, force=False,
                 outdir=None, stats=False, tag=None, extra_flags=(), roll=True, min_waves=0, lanes=1,
                 recip=False, fast_div=False, inline_max=0, reg_budget=150, scratch="auto", body="code",
-                waves=1, fuse=False, static_clean=False, forward=False, rcache=0, lds_state=0):
+                waves=1, fuse=False, static_clean=False, forward=False, rcache=0, lds_state=0, share=False):
     """Emit <cls>.hip (+ <cls>.h, <cls>.tape) and compile lib<cls>.so with hipcc for gfx950.
     Mirrors the createGateway/compile step of cmex2optimizeCS.m:403-417."""
     from .tapeio import save_tape
@@ -1252,7 +1365,8 @@ def build_class(spec, fp_contract="fast", arch="gfx950", opt="-O3", block=64, fo
     src, L = emit_class(spec, fp_contract=fp_contract, block=block, stats=stats, roll=roll,
                         min_waves=min_waves, lanes=lanes, recip=recip, fast_div=fast_div, inline_max=inline_max,
                         reg_budget=reg_budget, scratch=scratch, body=body, waves=waves, fuse=fuse,
-                        static_clean=static_clean, forward=forward, rcache=rcache, lds_state=lds_state)
+                        static_clean=static_clean, forward=forward, rcache=rcache, lds_state=lds_state,
+                        share=share)
     hip = os.path.join(outdir, f"{cls}{suffix}.hip")
     so = os.path.join(outdir, f"lib{cls}{suffix}.so")
     flags = [opt, f"--offload-arch={arch}", "-fPIC", "-shared", "-std=c++17",

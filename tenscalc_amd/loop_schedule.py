@@ -94,6 +94,7 @@ def analyse(tape, defines):
         ent[e["name"]] = (frozenset(e["parents"]), frozenset(e["children"]))
     sites_c, sites_d = {}, {}
     heads = []           # fixpoint state at the head of every loop, outermost last
+    backs = []           # ... and at the end of its body (the back edge)
 
     def meet(a, b):
         return (a[0] & b[0], a[1] & b[1])
@@ -120,9 +121,10 @@ def analyse(tape, defines):
                     if new == head:
                         break
                     head = new
-                run(nd[1], head, record)
+                back = run(nd[1], head, record)
                 if record:
                     heads.append(head)
+                    backs.append(back)
                 marks = [k for k, x in enumerate(nd[1]) if x[0] == "exit"]
                 if marks:      # left only at the markers (at least one pass)
                     sts = [run(nd[1][:k], head, False) for k in marks]
@@ -136,6 +138,8 @@ def analyse(tape, defines):
     allg = frozenset(range(1, tape.nGroups + 1))
     run(newton_program(defines), (frozenset(), allg), True)
     analyse.loop_head_dirty = set(heads[-1][1]) if heads else set()   # at the head of the Newton loop itself
+    analyse.loop_back_dirty = set(backs[-1][1]) if backs else set()   # at the end of a pass: nothing of these
+    #                                                                   groups is carried into the next pass
     return {k: set(v) for k, v in sites_c.items()}, {k: set(v) for k, v in sites_d.items()}
 
 
@@ -146,3 +150,71 @@ def _everywhere(nodes, st, run, meet):
         if nodes[k][0] in ("if", "loop"):
             acc = meet(acc, _everywhere(nodes[k][1], run(nodes[:k], st, False), run, meet))
     return acc
+
+
+# ---------------------------------------------------------------------------------------------------
+# life times of the values of transient groups (for slot sharing, lowering.Lowering(share=...))
+# ---------------------------------------------------------------------------------------------------
+def timeline(tape, defines):
+    """Linear time over one pass of the Newton loop body.
+
+    Returns dict(time={entry name: [positions]}, loops=[(first, last)] of the inner loops,
+    T_init=-1, T_end, E={group: sorted positions where it may be evaluated}, transient=set of groups
+    certainly dirty at the loop head).  Position -1 stands for the initialisation sequence, T_end for
+    what runs after the loop (getOutputs).  transient = groups certainly dirty at the END of a pass:
+    none of their values is carried into the next pass (the first pass may still find them clean from the
+    initialisation sequence, position -1)."""
+    clean, dirty = analyse(tape, defines)
+    transient = set(analyse.loop_back_dirty)
+    prog = newton_program(defines)
+    body = [nd for nd in prog if nd[0] == "loop"][-1][1]
+    init = [nd for nd in prog if nd[0] == "call"]
+    time, loops = {}, []
+    pos = [0]
+
+    def walk(nodes):
+        for nd in nodes:
+            if nd[0] == "call":
+                time.setdefault(nd[1], []).append(pos[0])
+                pos[0] += 1
+            elif nd[0] == "if":
+                walk(nd[1])
+            elif nd[0] == "loop":
+                a = pos[0]
+                walk(nd[1])
+                loops.append((a, pos[0] - 1))
+    walk(body)
+    T_end = pos[0]
+    for nd in init:
+        time.setdefault(nd[1], []).append(-1)
+    ent = {e["name"]: e for e in list(tape.gets) + list(tape.copies)}
+    E = {}
+    for nm, ts in time.items():
+        e = ent.get(nm)
+        if e is None:
+            continue
+        for g in e["parents"]:
+            if g not in clean.get(nm, ()):
+                E.setdefault(g, set()).update(ts)
+    # also transient: a group that is re-evaluated before every use -- certainly dirty at the first call of a
+    # pass that needs it, and elsewhere certainly clean only thanks to that evaluation earlier in the SAME
+    # pass; such a group never relies on what its storage held before (e.g. mu./F, evaluated for
+    # initDualIneq__ right after setMu__ and read by nothing else)
+    uses = {}
+    for nm, ts in time.items():
+        e = ent.get(nm)
+        if e is None:
+            continue
+        for g in e["parents"]:
+            what = "dirty" if g in dirty.get(nm, ()) else ("clean" if g in clean.get(nm, ()) else "dynamic")
+            for t in ts:
+                uses.setdefault(g, []).append((t, what))
+    for g, us in uses.items():
+        if g in transient or any(w == "dynamic" for _, w in us):
+            continue
+        first_dirty = min([t for t, w in us if w == "dirty" and t >= 0], default=None)
+        ok = all(w == "dirty" or (t >= 0 and first_dirty is not None and t > first_dirty) for t, w in us)
+        if ok:
+            transient.add(g)
+    return dict(time=time, loops=loops, T_init=-1, T_end=T_end, E={g: sorted(v) for g, v in E.items()},
+                transient=transient, clean=clean, dirty=dirty)

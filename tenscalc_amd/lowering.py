@@ -63,8 +63,12 @@ class DFamily:
 
 
 class Lowering:
-    def __init__(self, tape, code=None, roll=True, lanes=1, _replicate=(), mine=None, spill_all=False):
+    def __init__(self, tape, code=None, roll=True, lanes=1, _replicate=(), mine=None, spill_all=False,
+                 share=None):
         T = self.T = tape
+        # share: the solver #define block -> values of transient groups whose life times inside one pass of
+        # the Newton loop do not overlap share storage (_assign_shared_slots); None: one slot per value
+        self.share = share
         self.P = int(lanes)
         # spill_all: every computed value gets a memory slot (no inlining, no SSA temporaries): the
         # storage map of the table-driven back-end (interp_emitter), where instructions are data
@@ -206,22 +210,29 @@ class Lowering:
                     read_any[j] = True
         read_any |= out_needed
         pslot = np.full(n + 1, -1, dtype=np.int64)
-        k = 0
+        blocks = []                      # storage requests: lists of instruction ids that need consecutive slots
+        seen = np.zeros(n + 1, dtype=bool)
         for m in fam_members + mined:
-            for i in m:
-                if pslot[i] < 0 and not self.inline[i]:
-                    pslot[i] = k
-                    k += 1
+            blk = [int(i) for i in m if not seen[i] and not self.inline[i]]
+            if blk:
+                seen[blk] = True
+                blocks.append(blk)
         for i in range(1, n + 1):
-            if pslot[i] >= 0:
+            if seen[i]:
                 continue
             if T.isset[i - 1]:
                 if not self.external[i] and read_any[i]:
+                    blocks.append([i])
+            elif computed[i] and not self.local[i] and not self.inline[i] and i not in self.dval:
+                blocks.append([i])
+        if self.share is not None and not spill_all:
+            k = self._assign_shared_slots(blocks, pslot)
+        else:
+            k = 0
+            for blk in blocks:
+                for i in blk:
                     pslot[i] = k
                     k += 1
-            elif computed[i] and not self.local[i] and not self.inline[i] and i not in self.dval:
-                pslot[i] = k
-                k += 1
         self.pslot = pslot
         self.nPriv = k
         # an input stays distributed only if every reader consumes it aligned (member c of a
@@ -256,7 +267,8 @@ class Lowering:
                     if d["name"] in bad:
                         break
             if bad:
-                self.__init__(tape, code, roll, lanes, _replicate=self._replicate | bad, mine=self.mine)
+                self.__init__(tape, code, roll, lanes, _replicate=self._replicate | bad, mine=self.mine,
+                              share=self.share)
                 return
         # ---- verify families against the final storage -----------------------------------------------------
         self._tree_cache = {}
@@ -290,6 +302,102 @@ class Lowering:
     # -------------------------------------------------------------------------------------------
     def operands(self, i):
         return self._opl[self._ost[i - 1]:self._ost[i]]
+
+    # ---- slot sharing ---------------------------------------------------------------------------------
+    def _assign_shared_slots(self, blocks, pslot):
+        """Values of transient dependency groups (certainly dirty at the head of the Newton loop) live from
+        the first call that may evaluate their group to the last call that may evaluate a reader (or reads
+        them itself); two values whose life times inside one pass of the loop body are disjoint get the
+        same slot.  Everything else keeps a slot of its own: sets, copy destinations, groups that can stay
+        clean across iterations, and every loop-evaluated group that getOutputs -- which runs after the
+        loop, wherever the loop was left, and trusts the status flags -- depends on.
+
+        Why this is sound with the lazy-evaluation flags left as they are: (1) inside the loop a value is
+        read only while a reader group is being evaluated or by an entry point directly, and every
+        position where that may happen is inside the value's life time (the sets E come from the same
+        analysis that decides where groups are instantiated, and an inner loop counts as a whole);
+        (2) a flag can say "clean" for a group whose storage a later group has reused only after that
+        group's last possible reader, and before the next pass every transient group is invalidated;
+        (3) after the loop only getOutputs runs, and nothing it depends on shares storage unless it is
+        evaluated after the loop only.  The probe kernel (one get from scratch, all ancestors evaluated in
+        one go) has no such schedule: classes built with sharing do not support tc_probe."""
+        from .loop_schedule import timeline
+        T = self.T
+        tl = timeline(T, self.share)
+        E, transient, loops, T_end = tl["E"], tl["transient"], tl["loops"], tl["T_end"]
+        grp = T.group
+        readers = {}
+        for i in range(1, T.n + 1):
+            if T.used[i] and grp[i] > 0:
+                for j in set(self._opl[self._ost[i - 1]:self._ost[i]]):
+                    readers.setdefault(j, []).append(i)
+        direct = {}                          # instruction -> times at which an entry point reads it itself
+        keep = set()                         # groups that must keep storage of their own
+        for e in list(T.gets) + list(T.copies):
+            ts = tl["time"].get(e["name"])
+            if ts is None:                   # not called by the loop: getOutputs (and gets only probes use)
+                ts = [T_end]
+                keep |= {g_ for g_ in e["parents"] if E.get(g_)}
+            for j in list(e.get("src", [])) + [x for o in e.get("outputs", []) for x in o["ins"]]:
+                direct.setdefault(int(j), []).extend(ts)
+
+        # groups no entry point of the solver ever invalidates (they depend on the parameters only): evaluated
+        # once, in the first pass; a value of theirs that only other such groups read is dead after that
+        varying = set()
+        for e in list(T.sets) + list(T.copies):
+            if e["name"] in tl["time"]:
+                varying |= set(e["children"])
+
+        def once(i):
+            g = int(grp[i])
+            return (g > 0 and g not in varying and g not in keep and i not in direct and E.get(g)
+                    and all(int(grp[r]) not in varying and int(grp[r]) not in keep and E.get(int(grp[r]))
+                            for r in readers.get(i, [])))
+
+        def life(i):
+            g = int(grp[i])
+            if g == 0 or g in keep or (g not in transient and not once(i)):
+                return None
+            ts = list(E.get(g, [T_end]))
+            for r in readers.get(i, []):
+                ts += E.get(int(grp[r]), [T_end])
+            ts += direct.get(i, [])
+            # the initialisation sequence (position -1) is an epoch of its own: what it computes and the loop
+            # recomputes before use is dead in between
+            init = -1 in ts
+            ts = [t for t in ts if t >= 0]
+            if not ts:
+                return init, T_end + 1, T_end + 1
+            a, b = min(ts), max(ts)
+            for p_, q_ in loops:             # an inner loop is all or nothing: passes repeat
+                if a <= q_ and b >= p_:
+                    a, b = min(a, p_), max(b, q_)
+            return init, a, b
+
+        placed = []                          # (first slot, size, used by the initialisation, a, b)
+        size = 0
+        INF = 10 ** 9
+        for blk in blocks:
+            lives = [life(i) for i in blk]
+            if any(x is None for x in lives):
+                init, a, b = True, -INF, INF
+            else:
+                init, a, b = any(x[0] for x in lives), min(x[1] for x in lives), max(x[2] for x in lives)
+            nb = len(blk)
+            where = None
+            if a > -INF:
+                for s0 in sorted({0} | {p0 + sz for p0, sz, *_ in placed}):
+                    if all(not (p0 < s0 + nb and s0 < p0 + sz) or ((b < pa or pb < a) and not (init and pi))
+                           for p0, sz, pi, pa, pb in placed):
+                        where = s0
+                        break
+            if where is None:
+                where = size
+            for q, i in enumerate(blk):
+                pslot[i] = where + q
+            placed.append((where, nb, init, a, b))
+            size = max(size, where + nb)
+        return size
 
     def leaf(self, j):
         T = self.T

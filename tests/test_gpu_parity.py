@@ -136,7 +136,7 @@ def test_reference_c_surface_single_instance(libs, sls_spec, sls_tape_path):
     assert J.value == ref[0, 0] and np.array_equal(x, ref[0, 1:])
 
 
-@pytest.mark.parametrize("variant", ["sls_fast", "sls_w8", "sls_w8h", "sls_regs", "sls_regsl"])
+@pytest.mark.parametrize("variant", ["sls_fast", "sls_w8", "sls_w8h", "sls_regs", "sls_regsl", "sls_w8s"])
 def test_fast_build_within_stated_tolerance(libs, sls_spec, sls_tape_path, variant):
     """reassociating lowerings (fast, w8) and the hoisted tape (w8h, regs: tenscalc_amd/hoist.py) against
     the oracle running the REFERENCE tape"""
