@@ -39,10 +39,13 @@ def main():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--batch", type=int, default=65536, help="instances per GPU")
-    ap.add_argument("--variant", default=os.environ.get("TC_BENCH_VARIANT", "w8"), choices=["strict", "fast", "w8", "w8h", "regs", "regsl", "w8s"],
-                    help="strict: 1 thread/instance, -ffp-contract=off, bit-exact vs the oracle; fast: same with FMA; "
-                         "w8: 8 lanes/instance wave-cooperative lowering (default); w8h / regs: the hoisted tape "
-                         "(parameter-only contractions first) under w8 / the register-resident lowering")
+    ap.add_argument("--variant", default=os.environ.get("TC_BENCH_VARIANT", "w8s"), choices=["strict", "fast", "w8", "w8h", "regs", "regsl", "w8s"],
+                    help="strict: 1 thread/instance, -ffp-contract=off, the reference tape, bit-exact vs the oracle; fast: "
+                         "same with FMA; w8: 8 lanes/instance wave-cooperative lowering of the reference tape; w8s "
+                         "(default): the same lowering of the hoisted tape (parameter-only contractions first, "
+                         "tenscalc_amd/hoist.py) with the inputs streamed instead of register-resident and LDS slots "
+                         "shared by life time: 6 wavefronts per CU instead of 4; w8h / regs / regsl: other lowerings of "
+                         "the hoisted tape (DESIGN.md 3.6)")
     ap.add_argument("--cpu-sample", type=int, default=int(os.environ.get("TC_CPU_SAMPLE", "65536")))
     ap.add_argument("--no-cpu", action="store_true")
     args = ap.parse_args()
@@ -152,7 +155,10 @@ def main():
             "config": {"workload": "sls box-constrained LS N=100 n=8, batch=%d random (A,b) per GPU, fp64 "
                                    "(BASELINE.json configs[1])" % B,
                        "batch_per_gpu": B, "mu0": SOLVE_ARGS["mu0"], "maxIter": SOLVE_ARGS["maxIter"],
-                       "variant": args.variant, "solved_fraction": solved_per_step / (B * world),
+                       "variant": args.variant,
+                       "tape": ("hoisted (parameter-only contractions first); results within the stated tolerance of the "
+                                "reference tape, tests/test_gpu_parity.py" if args.variant in g.HOISTED else "reference"),
+                       "solved_fraction": solved_per_step / (B * world),
                        "iter_median": float(np.median(it)), "iter_max": int(it.max()),
                        "sharding": "independent instances per rank, RCCL all_gather of results only"},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
