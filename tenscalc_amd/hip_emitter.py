@@ -75,6 +75,7 @@ class Printer:
         self.fuse = fuse            # long sums over the inputs share ONE sweep (see fused_sweeps)
         self._fused = {}            # sum instruction id -> name of its accumulated value in this group
         self._fused_d = {}          # distributed reduction id -> (name of its per-lane partial sum, scale)
+        self._prefused = {}         # ... already accumulated by a sweep shared by several groups (kernel prologue)
         # store->load forwarding inside a group (lanes>1): a value just written to LDS by this lane is
         # read back from the register that holds it -- a replicated value by every later statement of
         # the group, element c_ of a lane-split family by the aligned member c_ of a later family --
@@ -191,13 +192,15 @@ class Printer:
         44 multiply-adds) instead of being held in ~230 registers by 44 separate expressions.  Per-lane
         term order is unchanged."""
         L = self.L
-        self._fused_d = {}
+        self._fused_d = dict(self._prefused)
         if L.P == 1 or not self.fuse:
             return ""
         nodes = []
-        for u in L.units[g - 1]:
-            if isinstance(u, (int, np.integer)):
-                self._dreduce_nodes(L.tree(int(u)), nodes)
+        for g_ in (g if isinstance(g, (list, tuple)) else [g]):
+            for u in L.units[g_ - 1]:
+                if isinstance(u, (int, np.integer)):
+                    self._dreduce_nodes(L.tree(int(u)), nodes)
+        nodes = [t for t in nodes if t.ins not in self._prefused]
 
         def streamed(t):
             return all(kind != "d" or (v[0] == "X" and not [x for x in L.inputs if x["dist"] and x["arr"] == v[1]][0].get("resident", True))
@@ -1044,6 +1047,8 @@ def emit_class(spec, fp_contract="fast", block=64, stats=False, roll=True, min_w
         if not e.get("external"):
             internal_children |= set(e["children"])
     prologue_push = push([g for g in Dg if g not in internal_children])
+    import re as _re
+    pushed_first = sorted(int(x) for x in _re.findall(r"TC_NEED\((\d+)\)", prologue_push))
 
     def inval(children):
         s = ""
@@ -1071,7 +1076,7 @@ def emit_class(spec, fp_contract="fast", block=64, stats=False, roll=True, min_w
     elide, sure = {}, {}
     if static_clean and not interp:
         from .loop_schedule import analyse
-        elide, sure = analyse(T, spec.defines)
+        elide, sure = analyse(T, spec.defines, pre_clean=pushed_first if (P.fuse and lanes > 1) else ())
     full = "_full" if elide else ""       # name suffix of the context-free twins
 
     def need(g, name, sfx):
@@ -1169,7 +1174,18 @@ def emit_class(spec, fp_contract="fast", block=64, stats=False, roll=True, min_w
             cnt = d["rest"] * d["K"]
             prologue += (f"  _Pragma(\"unroll\") for (int j = 0; j < {cnt}; j++) "
                          f"c.dX{d['arr']}[j] = Sd[((long)({d['off']} + j) * B + tid) * TC_P + c.lane];\n")
-    if prologue_push:
+    if prologue_push and P.fuse and lanes > 1 and pushed_first:
+        # the parameter-only distributed groups, evaluated once per solve right here: their sums over inputs
+        # that are not resident in registers share ONE sweep (A'A and A'b: one pass over A instead of two),
+        # their bodies follow inline
+        sweep = P.fused_dsweeps(pushed_first)
+        P._prefused = dict(P._fused_d)
+        prologue += "  { TC_UNPACK\n" + sweep
+        for g_ in pushed_first:
+            prologue += (f"  c.st[{(g_ - 1) >> 6}] |= 1ull << {(g_ - 1) & 63};\n" + P.group_body(g_))
+        prologue += "  }\n"
+        P._prefused = {}
+    elif prologue_push:
         prologue += "  { TC_UNPACK\n" + prologue_push + "  }\n"
     outs = T.entry(f"{cls}_getOutputs")[2]["outputs"]
     w.append("extern \"C\" __global__ void TC_LAUNCH_BOUNDS\n"

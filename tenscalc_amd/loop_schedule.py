@@ -81,7 +81,7 @@ def certainly_clean(tape, defines):
     return analyse(tape, defines)[0]
 
 
-def analyse(tape, defines):
+def analyse(tape, defines, pre_clean=()):
     """(clean, dirty): per entry point, the groups that are certainly clean / certainly dirty at
     every one of its call sites.  A certainly dirty group is evaluated there without testing its
     flag -- which also tells the compiler that last iteration's values of that group are dead."""
@@ -136,7 +136,8 @@ def analyse(tape, defines):
         return (clean, dirty)
 
     allg = frozenset(range(1, tape.nGroups + 1))
-    run(newton_program(defines), (frozenset(), allg), True)
+    pre = frozenset(pre_clean)       # groups the kernel prologue has already evaluated (parameter-only ones)
+    run(newton_program(defines), (pre, allg - pre), True)
     analyse.loop_head_dirty = set(heads[-1][1]) if heads else set()   # at the head of the Newton loop itself
     analyse.loop_back_dirty = set(backs[-1][1]) if backs else set()   # at the end of a pass: nothing of these
     #                                                                   groups is carried into the next pass
