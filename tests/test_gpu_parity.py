@@ -337,7 +337,9 @@ def test_template_branches_on_gpu(libs, tmp_path, kind):
     c = spec.classname
     ref, rst, rit = Oracle(tape).solve_batch({c + "_set_A": At.reshape(B, -1), c + "_set_b": b, c + "_set_x": x0},
                                              c + "_getOutputs", B, mu0=1e-2, maxIter=40)
-    for tag, exact in (("small_%s_strict" % kind, True), ("small_%s_w8" % kind, False)):
+    # strict_share: the bit-exact lowering with LDS/scratch slots shared by life time (soundness of the sharing)
+    for tag, exact in (("small_%s_strict" % kind, True), ("small_%s_strict_share" % kind, True),
+                       ("small_%s_w8" % kind, False)):
         obj = _load(libs[tag], B)
         obj.setP_A(At); obj.setP_b(b); obj.setV_x(x0)
         st, it, _ = obj.solve(mu0=1e-2, maxIter=40)
@@ -353,3 +355,23 @@ def test_template_branches_on_gpu(libs, tmp_path, kind):
             assert ok.mean() > 0.9 and (st[ok] == rst[ok]).all()
             d = np.abs(got[ok] - ref[ok])
             assert d[:, 0].max() <= 1e-4 and np.quantile(d.max(axis=1), 0.8) <= 1e-6 and d.max() <= 1e-2
+
+
+def test_slot_sharing_is_bit_exact(libs, sls_spec, sls_tape_path):
+    """Lowering._assign_shared_slots (values of transient groups with disjoint life times share storage) under
+    the bit-exact lowering of the REFERENCE tape: status, iteration counts and outputs identical to the
+    oracle, which gives every value its own slot -- for converging, maxIter-limited and NaN instances."""
+    B = 1500
+    A, b, x0 = sls_batch(B, seed0=77000)
+    A[3] *= np.nan
+    x0[5] = .06                                   # infeasible start
+    for maxIter in (30, 4):
+        obj = _load(libs["sls_strict_share"], B)
+        _set(obj, A, b, x0)
+        args = dict(SOLVE_ARGS, maxIter=maxIter)
+        st, it, _ = obj.solve(**args)
+        J, x = obj.getOutputs()
+        ref, rst, rit = _oracle_batch(sls_spec, sls_tape_path, A, b, x0, maxIter=maxIter)
+        assert np.array_equal(st, rst) and np.array_equal(it, rit)
+        assert np.array_equal(J.reshape(B), ref[:, 0], equal_nan=True)
+        assert np.array_equal(x.reshape(B, 8), ref[:, 1:], equal_nan=True)
