@@ -166,6 +166,8 @@ def cmex2optimizeCS(*, classname, objective, optimizationVariables, constraints=
         outputExpressions = [substitute(o, ph, val) for o in outputExpressions]
     # the reference returns structurally sparse <=2-D outputs as sparse mxArrays
     # (writeCfunctionpergroup.m:590-605,716-727); the batched interface always returns dense arrays
+    if rewrite is not None:
+        outputExpressions = [rewrite(o) for o in outputExpressions]
     outputExpressions = [tc.full(o) for o in outputExpressions]
     code.declareGet(outputExpressions, f"{classname}_getOutputs", list(outputNames))
 

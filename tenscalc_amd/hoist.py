@@ -9,10 +9,16 @@ makes more of the tape parameter-only by two algebraic identities on the express
 
   R1  tprod(P.., plus(t1,..,tn)) -> plus(tprod(P..,t1),..,tprod(P..,tn))   (linearity)
   R2  tprod(P.., tprod(Q.., x..)) -> tprod(tprod(P..,Q..), x..)           (re-association)
+  R3  norm2(t1+..+tn) -> sum_s <ts,ts> + 2 sum_{s<s'} <ts,ts'>            (then R1/R2 on every inner product)
 
 where P.., Q.. depend only on *slow* variables (the class parameters) and x.. on anything else.
 A rewrite is kept only if it lowers the per-iteration multiply-add count (dense estimate).  For
-sls the gradient becomes ``(2A'A) x - 2A'b`` with both coefficients evaluated once per solve.
+sls the gradient becomes ``(2A'A) x - 2A'b`` with both coefficients evaluated once per solve, and the
+cost ``norm2(A*x-b)`` becomes ``x'(A'A)x - 2(A'b)'x + b'b``: after the coefficients have been formed
+nothing reads A or b again (one pass over the inputs per solve).  R3 trades a sum of squares for a
+difference of larger numbers: the relative rounding error of the cost grows by about
+(|x'A'Ax|+2|b'Ax|+|b'b|)/|cost|, a few hundred for the benchmark data, i.e. ~1e-13 instead of 1e-16 --
+far inside the tolerance these classes are tested at, but it is a change of arithmetic like the others.
 
 The rewritten tape is a different sequence of fp64 operations: results agree with the reference
 tape to rounding (not bit for bit), so classes built with ``hoist=True`` are tested at the stated
@@ -99,9 +105,34 @@ class Hoister:
             r = f if all(x is y for x, y in zip(na, f.args)) else tc._rebuild(f, na)
             if r.op == "tprod" and not self.is_slow(r):
                 r = self._improve(r)
+            elif r.op == "norm2" and not self.is_slow(r):
+                r = self._expand_norm2(r)
         self._memo[f.idx] = r
         self._memo[r.idx] = r
         return r
+
+    def _expand_norm2(self, f):
+        """R3, kept only if the expanded form needs fewer per-evaluation multiply-adds"""
+        u = f.args[0]
+        if u.op != "plus" or not any(self.has_param(t) for t in u.args):
+            return f
+        idx = tuple(-(k + 1) for k in range(u.ndim))
+        pieces, signs = [], []
+        terms = list(zip(u.args, u.par))
+        for a in range(len(terms)):
+            ta, sa = terms[a]
+            pieces.append(self.rewrite(tc.tprod(ta, idx, ta, idx)))
+            signs.append(1)
+            for b in range(a + 1, len(terms)):
+                tb, sb = terms[b]
+                pieces.append(self.rewrite(tc.tprod(tc.Tconstant(2.0), (), ta, idx, tb, idx)))
+                signs.append(int(sa) * int(sb))
+        cand = tc.plus(pieces, signs)
+        cb, ca = self.fast_cost(f), self.fast_cost(cand)
+        if ca < cb:
+            self.log.append(("expand norm2", f.idx, cand.idx, cb, ca))
+            return cand
+        return f
 
     def _split_scalars(self, f):
         """slow c*tprod(A,B,..) -> c*(tprod(A,B,..)): the same canonical form _reassociate gives its
@@ -144,8 +175,30 @@ class Hoister:
                     for k, (p, ix) in enumerate(zip(f.args, inds)):
                         a += [t if k == j else p, ix]
                     terms.append(self.rewrite(tc.tprod(*a)))
-                return tc.plus(terms, o.par)
+                return self._factor_out_scalar(terms, o.par)
         return None
+
+    @staticmethod
+    def _factor_out_scalar(terms, signs):
+        """c*a - c*b -> c*(a - b) for a numeric scalar c common to all terms: otherwise a parameter-only
+        term like 2*(A'b) is stored next to the A'b other expressions share"""
+        def split(t):
+            if t.op != "tprod":
+                return None
+            inds, _ = t.par
+            for k, o in enumerate(t.args):
+                if o.size == () and tc.const_value(o) is not None:
+                    rest = []
+                    for j, (p, ix) in enumerate(zip(t.args, inds)):
+                        if j != k:
+                            rest += [p, ix]
+                    return float(tc.const_value(o)), (tc.tprod(*rest) if rest else tc.Tones(()))
+            return None
+        parts = [split(t) for t in terms]
+        if len(terms) < 2 or any(p is None for p in parts) or len({p[0] for p in parts}) != 1 or parts[0][0] == 1.0:
+            return tc.plus(terms, signs)
+        inner = tc.plus([p[1] for p in parts], signs)
+        return tc.tprod(tc.Tconstant(parts[0][0]), (), inner, tuple(range(1, inner.ndim + 1)))
 
     def _reassociate(self, f):
         """R2: flatten fast tprod factors into this tprod, then contract all slow factors first."""
@@ -179,18 +232,14 @@ class Hoister:
         inner_l = [i for i in slow_labels if i < 0 and i not in fast_labels]
         mmap = {i: n + 1 for n, i in enumerate(sorted(outer_l, key=lambda i: (i < 0, abs(i))))}
         mmap.update({i: -(n + 1) for n, i in enumerate(inner_l)})
-        # the contraction of the non-scalar slow factors first, scalar factors applied to its (few)
-        # entries afterwards: sum_k A_ki*A_kj*2 would cost one more multiplication per term
+        # the contraction of the non-scalar slow factors first: sum_k A_ki*A_kj*2 would cost one more
+        # multiplication per term
         margs = []
         for k in big:
             margs += [objs[k], tuple(mmap[i] for i in labs[k])]
         M = tc.tprod(*margs)
-        scal = [k for k in slow if objs[k].size == ()]
-        if scal:
-            sargs = []
-            for k in scal:
-                sargs += [objs[k], ()]
-            M = tc.tprod(*(sargs + [M, tuple(range(1, M.ndim + 1))]))
+        scal = [k for k in slow if objs[k].size == ()]     # stay in the outer product: 2*(A'A) would be a second
+        #                                                    stored copy of A'A next to the one other uses share
         m_out = tuple(sorted(outer_l, key=lambda i: mmap[i]))
         # renumber the summation labels that survive in the outer product
         keep_neg = []
@@ -200,6 +249,8 @@ class Hoister:
         omap = {i: -(n + 1) for n, i in enumerate(keep_neg)}
         rel = lambda t: tuple(omap.get(i, i) for i in t)                 # noqa: E731
         oargs = [M, rel(m_out)] if M.size != () or tc.const_value(M) is None else [M, ()]
+        for k in scal:
+            oargs += [objs[k], ()]
         for k in fast:
             oargs += [objs[k], rel(labs[k])]
         return tc.tprod(*oargs)

