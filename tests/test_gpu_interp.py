@@ -57,6 +57,21 @@ def test_sls_interp_bit_exact(libs, sls_spec, tmp_path):
     assert np.array_equal(got, ref)
 
 
+@pytest.mark.parametrize("variant", ["sls_interp4", "sls_interp8", "sls_interp16"])
+def test_sls_interp_cooperating_waves_bit_exact(libs, sls_spec, tmp_path, variant):
+    """W wavefronts of a block share the 64 instances of a tile and split the records of every level
+    (barrier records between levels): same bits as one wavefront per tile and as the oracle"""
+    from tenscalc_amd.problems.sls import SOLVE_ARGS, sls_data
+    B = 130
+    data = []
+    for k in range(B):
+        A, b, x0 = sls_data(4000 + k)
+        data.append(dict(A=A, b=b, x=x0))
+    (st, it, got), (rst, rit, ref), _ = _solve_both(sls_spec, libs[variant], data, SOLVE_ARGS, B, tmp_path, variant)
+    assert np.array_equal(st, rst) and np.array_equal(it, rit) and (st == 0).all()
+    assert np.array_equal(got, ref)
+
+
 def test_dcmotor_interp_bit_exact(libs, tmp_path):
     import __graft_entry__ as g
     from tenscalc_amd.problems.mpc_dcmotor import SOLVE_ARGS, dcmotor_data, mpc_dcmotor
