@@ -2,6 +2,7 @@
 rewritten expressions must evaluate to the same numbers (to rounding) as the originals through
 the same scalarizer + CPU oracle, and must lower the per-iteration work."""
 import numpy as np
+import pytest
 
 import tenscalc_amd.tcalculus as tc
 from tenscalc_amd.hoist import Hoister
@@ -85,3 +86,37 @@ def test_cost_is_expanded_into_a_quadratic_form(tape_oracle):
         np.testing.assert_allclose(got["J2"], want, rtol=2e-12)
         worst = max(worst, abs(float(got["J2"]) - want) / want)
     assert worst < 1e-12
+
+
+def test_hoist_is_a_no_op_where_there_is_nothing_to_hoist(native_built, tmp_path):
+    """mpc_dcmotor has no product of parameter arrays with the optimisation variables: identical tape"""
+    from tenscalc_amd.problems.mpc_dcmotor import mpc_dcmotor
+    a = mpc_dcmotor(folder=str(tmp_path), classname="tmp_dc_a").tape
+    b = mpc_dcmotor(folder=str(tmp_path), classname="tmp_dc_b", hoist=True).tape
+    assert np.array_equal(a.types, b.types) and np.array_equal(a.ops, b.ops) and np.array_equal(a.pars, b.pars)
+
+
+@pytest.mark.parametrize("kind", ["box", "eq", "eqonly", "free"])
+def test_hoisted_solver_agrees_with_the_reference_tape(native_built, tmp_path, kind):
+    """whole solves through the oracle, reference tape vs hoisted tape, on the small problems that cover the
+    template branches (equality constraints: second LDL and nu; nF==0; unconstrained)"""
+    from tenscalc_amd.tapeio import save_tape
+    from oracle.tc_oracle import Oracle
+    from test_solver_options import _problem
+    rs = np.random.RandomState(8)
+    B = 40
+    A = rs.random_sample((B, 12, 4)); b = rs.random_sample((B, 12)); x0 = .02 * rs.random_sample((B, 4)) + .005
+    At = np.ascontiguousarray(np.transpose(A, (0, 2, 1))).reshape(B, -1)
+    res = []
+    for hoist in (False, True):
+        spec = _problem(kind, hoist=hoist)
+        tape = str(tmp_path / ("t%d.tape" % hoist))
+        save_tape(spec.tape, tape)
+        c = spec.classname
+        res.append(Oracle(tape).solve_batch({c + "_set_A": At, c + "_set_b": b, c + "_set_x": x0}, c + "_getOutputs", B,
+                                            mu0=1e-2, maxIter=40))
+    (o0, s0, i0), (o1, s1, i1) = res
+    assert np.array_equal(s0, s1) and np.abs(i0 - i1).max() <= 2
+    ok = s0 == 0
+    assert ok.mean() > 0.9
+    assert np.abs(o0[ok] - o1[ok]).max() <= 1e-4 and np.quantile(np.abs(o0[ok] - o1[ok]).max(axis=1), 0.8) <= 1e-7
