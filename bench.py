@@ -12,7 +12,6 @@ collective is the gather of results (outputs + status) over RCCL, included in th
 N>1.  Rank 0 prints ONE JSON line (see DESIGN.md "Measurement" for the roofline arithmetic).
 """
 import argparse
-import ctypes
 import json
 import os
 import sys
@@ -72,7 +71,7 @@ def main():
     cdev = torch.device("cpu") if single else dev
 
     import __graft_entry__ as g
-    from tenscalc_amd.problems.sls import SOLVE_ARGS, sls
+    from tenscalc_amd.problems.sls import SOLVE_ARGS
     from tenscalc_amd.runtime import LAYOUT_BATCH_MINOR, HipSolver
     spec = g.sls_spec(args.variant)
     kw = dict(g.VARIANT_KW[args.variant])
