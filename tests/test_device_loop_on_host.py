@@ -20,7 +20,8 @@ def both(sls_spec, sls_tape_path):
 
 
 @pytest.mark.parametrize("mu0,maxIter,eps", [(1.0, 30, 1e-9), (1e-3, 30, 1e-9), (1.0, 5, 1e-9), (1.0, 1, 1e-9),
-                                             (10.0, 60, 1e-3), (1.0, 30, 1e-20), (1e3, 12, 1e-9)])
+                                             (10.0, 60, 1e-3), (1.0, 30, 1e-20), (1e3, 12, 1e-9),
+                                             (1.0, 30, -10.0), (1.0, 40, -1.0)])   # < 0: second regularisation pass
 def test_sls_status_iter_outputs_bitwise(both, mu0, maxIter, eps):
     o, do, c = both
     stats = set()
@@ -76,9 +77,10 @@ def test_template_branches_bitwise(native_built, tmp_path, kind, opt):
         if trial >= 6:
             A = A * 1e4                           # badly scaled: regularisation retries, small steps
         r = []
+        ae = (-5.0, -5.0) if trial == 4 else (1e-9, 1e-9)     # negative: second regularisation pass
         for q in (o, do):
             q.set(c + "_set_A", A); q.set(c + "_set_b", b); q.set(c + "_set_x", x0)
-            st, it = q.solve(1.0 if trial % 2 else 1e-2, 40 if trial != 5 else 3, -1, (1e-9, 1e-9))
+            st, it = q.solve(1.0 if trial % 2 else 1e-2, 40 if trial != 5 else 3, -1, ae)
             r.append((st, it, q.get(c + "_getOutputs")))
         assert r[0][:2] == r[1][:2], (kind, opt, trial, r[0][:2], r[1][:2])
         assert np.array_equal(r[0][2], r[1][2], equal_nan=True)

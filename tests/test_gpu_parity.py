@@ -365,13 +365,15 @@ def test_slot_sharing_is_bit_exact(libs, sls_spec, sls_tape_path):
     A, b, x0 = sls_batch(B, seed0=77000)
     A[3] *= np.nan
     x0[5] = .06                                   # infeasible start
-    for maxIter in (30, 4):
+    # addEye2Hessian < 0: negative curvature, the second pass of the regularisation loop runs (the only case in
+    # which groups are re-evaluated inside one Newton iteration after a set)
+    for maxIter, ae in ((30, (1e-9, 1e-9)), (4, (1e-9, 1e-9)), (30, (-10.0, -10.0)), (30, (-1.0, -1.0))):
         obj = _load(libs["sls_strict_share"], B)
         _set(obj, A, b, x0)
-        args = dict(SOLVE_ARGS, maxIter=maxIter)
+        args = dict(SOLVE_ARGS, maxIter=maxIter, addEye2Hessian=ae)
         st, it, _ = obj.solve(**args)
         J, x = obj.getOutputs()
-        ref, rst, rit = _oracle_batch(sls_spec, sls_tape_path, A, b, x0, maxIter=maxIter)
+        ref, rst, rit = _oracle_batch(sls_spec, sls_tape_path, A, b, x0, maxIter=maxIter, addEye2Hessian=ae)
         assert np.array_equal(st, rst) and np.array_equal(it, rit)
         assert np.array_equal(J.reshape(B), ref[:, 0], equal_nan=True)
         assert np.array_equal(x.reshape(B, 8), ref[:, 1:], equal_nan=True)

@@ -18,7 +18,9 @@ def both(sls_spec, sls_tape_path):
 
 
 @pytest.mark.parametrize("mu0,maxIter,eps", [(1.0, 30, 1e-9), (1e-3, 30, 1e-9), (1.0, 5, 1e-9),
-                                             (10.0, 60, 1e-3), (1.0, 30, 1e-20)])
+                                             (10.0, 60, 1e-3), (1.0, 30, 1e-20),
+                                             (1.0, 30, -10.0), (1.0, 40, -1.0)])   # < 0: negative curvature, the
+#                                              second pass of the regularisation loop (ipmPD_CSsolver.c:459-531) runs
 def test_status_iter_outputs_bitwise(both, mu0, maxIter, eps):
     o, ro, c = both
     for seed in range(100, 140):
