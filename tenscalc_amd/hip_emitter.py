@@ -646,6 +646,11 @@ class Printer:
                         ek = _re.sub(r"@FW(\w+)@", lambda m_: f"{m_.group(1)}_{k}", e)
                         if (k + 1) * L.P <= u.n:
                             out.append(f"  {{ const int c_ = lane + {k * L.P}; {{ {nm}_{k} = {ek}; MM({dst}) = {nm}_{k}; }} }}\n")
+                        elif "SX(" in ek or "TC_SD(" in ek or "c.Sd" in ek:
+                            # the members read global memory: lanes past the end must not (an index past the
+                            # input block is an out-of-bounds HBM access, not a harmless LDS read)
+                            out.append(f"  {{ const int c_ = lane + {k * L.P}; if (c_ < {u.n}) {{ {nm}_{k} = {ek}; "
+                                       f"MM({dst}) = {nm}_{k}; }} }}\n")
                         else:
                             # ragged tail without a branch: the lanes past the end compute on whatever the
                             # next slots hold and park the result in a spare slot nobody reads
