@@ -937,10 +937,13 @@ def emit_class(spec, fp_contract="fast", block=64, stats=False, roll=True, min_w
              "  const __attribute__((address_space(1))) char *Sdb;\n  unsigned sdo8, sdB8;\n"
              "  unsigned long long st[TC_NSTW];\n" + (f"  double rv[{nrv}];\n" if nrv else "") + dmembers +
              "#ifdef TC_STATS\n  int nMinF;\n  long long cyc[TC_NGROUPS];\n  int cnt[TC_NGROUPS];\n#endif\n};\n"
-             f"#define SX(k) (S[(long)(k) * B])\n#define MM(k) {mm}\n#define ML(j) (c.ls[(j) * TC_BLOCK])\n"
+             # input reads are clamped to the input block: every index the emitter prints is in range (constants
+             # fold away), the clamp is the backstop for a lane of a split loop that should have been masked
+             "#define SX(k) (S[(long)((k) < TC_NEXT ? (k) : (TC_NEXT > 0 ? TC_NEXT - 1 : 0)) * B])\n"
+             f"#define MM(k) {mm}\n#define ML(j) (c.ls[(j) * TC_BLOCK])\n"
              "// element j of this lane's share of a distributed input that is not resident in registers;\n"
              "// 32-bit byte offsets: the host refuses batches whose distributed block reaches 4 GiB (TC_SD32)\n"
-             "#define TC_SD(j) (*(tc_glob)(c.Sdb + (unsigned)((unsigned)(j) * c.sdB8 + c.sdo8)))\n"
+             "#define TC_SD(j) (*(tc_glob)(c.Sdb + (unsigned)((unsigned)((j) < TC_NDIST ? (j) : (TC_NDIST > 0 ? TC_NDIST - 1 : 0)) * c.sdB8 + c.sdo8)))\n"
              "#define TC_UNPACK tc_mem m = c.m; tc_glob S = c.S; const long B = c.B; const int lane = c.lane; (void)m; (void)S; (void)B; (void)lane;\n"
              "#define TC_NUM(x, d) (x)\n"
              + ("// opt-in fast division: hardware reciprocal + two Newton steps + one residual correction\n"
