@@ -112,6 +112,38 @@ def test_strict_edge_cases_status_bits(libs, sls_spec, sls_tape_path):
     assert st[0] == rst[0] and it[0] == rit[0] and np.array_equal(one.getOutputs()[1].reshape(1, 8), ref[:, 1:])
 
 
+@pytest.mark.parametrize("variant", ["sls_w8", "sls_w8s"])
+def test_wave_cooperative_edge_cases(libs, sls_spec, sls_tape_path, variant):
+    """the benchmarked lowerings on the inputs that exercise the status bits: NaN parameters (status 4 in that
+    instance only -- its lane group must not disturb the 7 other instances of its wavefront), an infeasible start
+    (status 1), maxIter exhaustion (status 8|...), an extreme scale, B not a multiple of 8 and B=1.  Status codes
+    of these instances equal the oracle's; the ordinary ones agree within the stated tolerance."""
+    B = 131
+    A, b, x0 = sls_batch(B, seed0=5000)
+    A[3] *= np.nan
+    b[5] *= 1e6
+    x0[9] = .06                                   # outside the box: min F <= 0 at the first test
+    for kw in [dict(mu0=1.0, maxIter=30), dict(mu0=1.0, maxIter=4)]:
+        obj = _load(libs[variant], B)
+        _set(obj, A, b, x0)
+        st, it, _ = obj.solve(**{**SOLVE_ARGS, **kw})
+        J, x = obj.getOutputs()
+        x = x.reshape(B, 8)
+        ref, rst, rit = _oracle_batch(sls_spec, sls_tape_path, A, b, x0, **kw)
+        assert st[3] == 4 == rst[3] and st[9] == rst[9] == 1
+        assert np.array_equal(st, rst), kw
+        ordinary = np.ones(B, dtype=bool)
+        ordinary[[3, 5, 9]] = False
+        assert np.abs(it - rit)[ordinary].max() <= 2
+        assert np.abs(x - ref[:, 1:])[ordinary].max() <= 5e-5
+    one = _load(libs[variant], 1)
+    _set(one, A[:1], b[:1], x0[:1])
+    st, it, _ = one.solve(**SOLVE_ARGS)
+    ref, rst, rit = _oracle_batch(sls_spec, sls_tape_path, A[:1], b[:1], x0[:1])
+    assert st[0] == rst[0] and abs(int(it[0]) - int(rit[0])) <= 2
+    assert np.abs(one.getOutputs()[1].reshape(1, 8) - ref[:, 1:]).max() <= 5e-5
+
+
 def test_reference_c_surface_single_instance(libs, sls_spec, sls_tape_path):
     """the reference's own C symbols (<cls>_set_*, ipmPD_CSsolver, <cls>_getOutputs) at B=1"""
     import ctypes
