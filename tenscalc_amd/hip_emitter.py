@@ -82,6 +82,7 @@ class Printer:
         # instead of through an LDS round trip the compiler cannot remove (it does not know that the
         # other lanes of the instance write other slots)
         self.forward = False
+        self.branch_free_tails = True
         self._rv = {}               # slot -> index into c.rv[]: register copy that outlives the group (setup_rcache)
         self._fw_rep = {}           # slot -> name of the register copy (replicated values)
         self._fw_fam = {}           # (first slot, slot stride) -> (name prefix of per-block copies, members)
@@ -646,7 +647,7 @@ class Printer:
                         ek = _re.sub(r"@FW(\w+)@", lambda m_: f"{m_.group(1)}_{k}", e)
                         if (k + 1) * L.P <= u.n:
                             out.append(f"  {{ const int c_ = lane + {k * L.P}; {{ {nm}_{k} = {ek}; MM({dst}) = {nm}_{k}; }} }}\n")
-                        elif "SX(" in ek or "TC_SD(" in ek or "c.Sd" in ek:
+                        elif not self.branch_free_tails or "SX(" in ek or "TC_SD(" in ek or "c.Sd" in ek:
                             # the members read global memory: lanes past the end must not (an index past the
                             # input block is an out-of-bounds HBM access, not a harmless LDS read)
                             out.append(f"  {{ const int c_ = lane + {k * L.P}; if (c_ < {u.n}) {{ {nm}_{k} = {ek}; "
@@ -819,8 +820,12 @@ def _mask(groups):
 
 def emit_class(spec, fp_contract="fast", block=64, stats=False, roll=True, min_waves=0, lanes=1,
                recip=False, fast_div=False, inline_max=0, reg_budget=150, scratch="auto", body="code",
-               waves=1, fuse=False, static_clean=False, forward=False, rcache=0, lds_state=0, share=False):
+               waves=1, fuse=False, static_clean=False, forward=False, rcache=0, lds_state=0, share=False,
+               branch_free_tails=True):
     """Return the HIP source text of the solver class.
+
+    branch_free_tails=False: ragged tails of lane-split families keep their predicate; saves the spare LDS slot
+    and the tail pad the branch-free form needs (sls/w8s: exactly the difference between 6 and 7 wavefronts per CU).
 
     share=True: values of transient groups with disjoint life times inside a pass of the Newton loop share
     storage (Lowering._assign_shared_slots); such classes do not support tc_probe.
@@ -860,6 +865,7 @@ def emit_class(spec, fp_contract="fast", block=64, stats=False, roll=True, min_w
         raise ValueError("block must be a multiple of lanes")
     P = Printer(L, roll=roll, recip=recip, fuse=fuse)
     P.forward = bool(forward) and lanes > 1
+    P.branch_free_tails = bool(branch_free_tails)
     nrv = P.setup_rcache(rcache) if (P.forward and not interp) else 0
     if nrv:
         inline_max = 10 ** 9        # the register copies live in the kernel's context: every group inlined
@@ -889,14 +895,15 @@ def emit_class(spec, fp_contract="fast", block=64, stats=False, roll=True, min_w
     if interp:
         from . import interp_schedule as isch
         consts = isch.constant_rows(T, L)[0]
-    nmp = max(1, L.nPriv) + (1 if forward and lanes > 1 else 0)   # + TC_DUMMY
+    dummy = 1 if (forward and lanes > 1 and branch_free_tails) else 0
+    nmp = max(1, L.nPriv) + dummy                                  # + TC_DUMMY
     nmp += int(os.environ.get("TC_LDS_PAD_SLOTS", "0"))      # occupancy experiments only
     # per-instance stride = 8 mod 16 doubles: the 4 instances of a half-wave start 16 banks apart either way
     # (8 mod 32: 0,16,32,48; 24 mod 32: 0,48,32,16), so broadcast reads and 8-lane reads of consecutive
     # slots are conflict-free
     nmp += (8 - nmp) % 16
     w.append(f"#define TC_NM {max(1, L.nPriv + len(consts))}\n#define TC_NMP {nmp}\n#define TC_NEXT {L.nExt}\n#define TC_NOUT {nOut}\n"
-             f"#define TC_NGROUPS {T.nGroups}\n#define TC_NSTW {nW}\n#define TC_DUMMY {max(1, L.nPriv)}\n\n")
+             f"#define TC_NGROUPS {T.nGroups}\n#define TC_NSTW {nW}\n#define TC_DUMMY {max(1, L.nPriv)}\n#define TC_LDS_TAIL {8 if dummy else 0}\n\n")
     dmembers = ""
     # register budget for lane-distributed inputs (doubles per lane); larger inputs stay in HBM
     budget = reg_budget
@@ -1165,7 +1172,7 @@ def emit_class(spec, fp_contract="fast", block=64, stats=False, roll=True, min_w
                 "#if defined(TC_SCRATCH_GLOBAL)\n  c.m = (tc_gmem)(Mg + ((tid >> 6) * (long)(TC_NEXT + TC_NM) + TC_NEXT) * 64 + (tid & 63));\n"
                 "#elif TC_P == 1\n  double mm_[TC_NM];\n  c.m = (tc_priv)mm_;\n"
                 "#ifdef TC_NLS\n  __shared__ double tc_lds_s[TC_NLS * TC_BLOCK];\n  c.ls = (tc_lds)&tc_lds_s[threadIdx.x];\n#endif\n"
-                "#else\n  __shared__ double tc_lds_m[TC_NMP * TC_G + 8];   // + 8: reads past a ragged family tail of the last instance\n"
+                "#else\n  __shared__ double tc_lds_m[TC_NMP * TC_G + TC_LDS_TAIL];   // tail: reads past a ragged family tail of the last instance\n"
                 "  c.m = (tc_lds)&tc_lds_m[(threadIdx.x / TC_P) * TC_NMP];\n#endif\n"
                 "  c.lane = (int)(t_ % TC_P);\n  c.S = (tc_glob)(S + tid);\n  c.B = B;\n"
                 "  for (int k = 0; k < TC_NSTW; k++) c.st[k] = 0;\n"
@@ -1378,7 +1385,8 @@ def class_header(spec):
 def build_class(spec, fp_contract="fast", arch="gfx950", opt="-O3", block=64, force=False,
                 outdir=None, stats=False, tag=None, extra_flags=(), roll=True, min_waves=0, lanes=1,
                 recip=False, fast_div=False, inline_max=0, reg_budget=150, scratch="auto", body="code",
-                waves=1, fuse=False, static_clean=False, forward=False, rcache=0, lds_state=0, share=False):
+                waves=1, fuse=False, static_clean=False, forward=False, rcache=0, lds_state=0, share=False,
+                branch_free_tails=True):
     """Emit <cls>.hip (+ <cls>.h, <cls>.tape) and compile lib<cls>.so with hipcc for gfx950.
     Mirrors the createGateway/compile step of cmex2optimizeCS.m:403-417."""
     from .tapeio import save_tape
@@ -1390,7 +1398,7 @@ def build_class(spec, fp_contract="fast", arch="gfx950", opt="-O3", block=64, fo
                         min_waves=min_waves, lanes=lanes, recip=recip, fast_div=fast_div, inline_max=inline_max,
                         reg_budget=reg_budget, scratch=scratch, body=body, waves=waves, fuse=fuse,
                         static_clean=static_clean, forward=forward, rcache=rcache, lds_state=lds_state,
-                        share=share)
+                        share=share, branch_free_tails=branch_free_tails)
     hip = os.path.join(outdir, f"{cls}{suffix}.hip")
     so = os.path.join(outdir, f"lib{cls}{suffix}.so")
     flags = [opt, f"--offload-arch={arch}", "-fPIC", "-shared", "-std=c++17",

@@ -16,6 +16,8 @@ Values used once inside their own dependency group are inlined into the consumer
 """
 from __future__ import annotations
 
+import os
+
 import numpy as np
 
 from . import instructions as I
@@ -63,6 +65,12 @@ class DFamily:
 
 
 class Lowering:
+    # slot sharing: exempt volatile values from surviving a whole inner loop (see life()).  Sound (CPU replay of
+    # real call traces, bit-exact on the GPU) and worth 26 slots on sls -- a seventh wavefront per CU -- but the
+    # tighter reuse costs as much as the wavefront gains (0.72 vs 0.66 ms at equal occupancy, 0.66 at 7 per CU):
+    # off by default, TC_FINE_LIVES=1 to enable
+    FINE_LIVES = os.environ.get("TC_FINE_LIVES", "0") == "1"
+
     def __init__(self, tape, code=None, roll=True, lanes=1, _replicate=(), mine=None, spill_all=False,
                  share=None):
         T = self.T = tape
@@ -335,9 +343,12 @@ class Lowering:
         keep = set()                         # groups that must keep storage of their own
         for e in list(T.gets) + list(T.copies):
             ts = tl["time"].get(e["name"])
-            if ts is None:                   # not called by the loop: getOutputs (and gets only probes use)
+            if ts is None:                   # not called by the loop
                 ts = [T_end]
-                keep |= {g_ for g_ in e["parents"] if E.get(g_)}
+                if e["name"].endswith("_getOutputs"):
+                    keep |= {g_ for g_ in e["parents"] if E.get(g_)}
+                else:                            # a get only the probe kernel would call: classes built with
+                    continue                     # sharing have none (hip_emitter: no probes), nothing reads it
             for j in list(e.get("src", [])) + [x for o in e.get("outputs", []) for x in o["ins"]]:
                 direct.setdefault(int(j), []).extend(ts)
 
@@ -354,13 +365,42 @@ class Lowering:
                     and all(int(grp[r]) not in varying and int(grp[r]) not in keep and E.get(int(grp[r]))
                             for r in readers.get(i, [])))
 
+        # positions inside a call: the groups an entry point may evaluate run in the order of its parents list,
+        # the entry point's own reads come last
+        Epos = {}
+        for e in list(T.gets) + list(T.copies):
+            for t in tl["time"].get(e["name"], []):
+                for k, g_ in enumerate(e["parents"]):
+                    if g_ not in tl["clean"].get(e["name"], ()):
+                        Epos.setdefault(g_, []).append(t + (k + 1) / 4096.0 if t >= 0 else -1)
+        for j in direct:
+            direct[j] = [t + 0.9999 if 0 <= t < T_end else t for t in direct[j]]
+        # an inner loop repeats: what a later pass may read WITHOUT re-evaluating it must survive the whole loop.
+        # Exempt are values of groups that every invalidating set inside the loop invalidates ("volatile"),
+        # unless an entry point inside the loop reads them itself.  A further pass either follows such a set --
+        # then every volatile group is dirty and is re-evaluated, in order, before anything reads it, and
+        # non-volatile groups (clean) are neither evaluated nor do they read -- or it follows sets without
+        # dependants only -- then nothing is evaluated and nothing is written, and only the entry points' own
+        # reads happen again (those values are not exempt).  E.g. the LDL factor is dead once the triangular
+        # solves have run and shares its slots with what the direction-error test computes next.
+        volatile = []
+        for p_, q_ in loops:
+            inside = [e for e in list(T.sets) + list(T.copies)
+                      if e["children"] and any(p_ <= t <= q_ for t in tl["time"].get(e["name"], []))]
+            v = set.intersection(*[set(e["children"]) for e in inside]) if inside else set()
+            volatile.append(v)
+
+        def exempt(i, g, k):
+            p_, q_ = loops[k]
+            return g in volatile[k] and not any(p_ <= t < q_ + 1 for t in direct.get(i, []))
+
         def life(i):
             g = int(grp[i])
             if g == 0 or g in keep or (g not in transient and not once(i)):
                 return None
-            ts = list(E.get(g, [T_end]))
+            ts = list(Epos.get(g, [T_end]))
             for r in readers.get(i, []):
-                ts += E.get(int(grp[r]), [T_end])
+                ts += Epos.get(int(grp[r]), [T_end])
             ts += direct.get(i, [])
             # the initialisation sequence (position -1) is an epoch of its own: what it computes and the loop
             # recomputes before use is dead in between
@@ -369,34 +409,56 @@ class Lowering:
             if not ts:
                 return init, T_end + 1, T_end + 1
             a, b = min(ts), max(ts)
-            for p_, q_ in loops:             # an inner loop is all or nothing: passes repeat
-                if a <= q_ and b >= p_:
-                    a, b = min(a, p_), max(b, q_)
+            for k, (p_, q_) in enumerate(loops):
+                if a < q_ + 1 and b >= p_ and not (self.FINE_LIVES and exempt(i, g, k)):
+                    if self.FINE_LIVES and g in volatile[k] and a >= p_:
+                        # volatile, but an entry point inside the loop reads it: a further pass without any
+                        # evaluation reads it again, so it must last to the end of the loop -- but nothing can
+                        # overwrite it between the loop head and its own position in such a pass (nothing is
+                        # written at all), and in a pass that does evaluate it is recomputed first
+                        b = max(b, q_ + 0.99999)
+                    else:
+                        a, b = min(a, p_), max(b, q_ + 0.99999)
             return init, a, b
 
-        placed = []                          # (first slot, size, used by the initialisation, a, b)
-        size = 0
         INF = 10 ** 9
+        req = []                             # (block, used by the initialisation, a, b)
         for blk in blocks:
             lives = [life(i) for i in blk]
             if any(x is None for x in lives):
-                init, a, b = True, -INF, INF
+                req.append((blk, True, -INF, INF))
             else:
-                init, a, b = any(x[0] for x in lives), min(x[1] for x in lives), max(x[2] for x in lives)
-            nb = len(blk)
-            where = None
-            if a > -INF:
-                for s0 in sorted({0} | {p0 + sz for p0, sz, *_ in placed}):
-                    if all(not (p0 < s0 + nb and s0 < p0 + sz) or ((b < pa or pb < a) and not (init and pi))
-                           for p0, sz, pi, pa, pb in placed):
-                        where = s0
-                        break
-            if where is None:
-                where = size
+                req.append((blk, any(x[0] for x in lives), min(x[1] for x in lives), max(x[2] for x in lives)))
+
+        def pack(order):
+            placed, where_of, size = [], {}, 0           # placed: (first slot, size, init, a, b)
+            for n_ in order:
+                blk, init, a, b = req[n_]
+                nb = len(blk)
+                where = None
+                if a > -INF:
+                    for s0 in sorted({0} | {p0 + sz for p0, sz, *_ in placed}):
+                        if all(not (p0 < s0 + nb and s0 < p0 + sz) or ((b < pa or pb < a) and not (init and pi))
+                               for p0, sz, pi, pa, pb in placed):
+                            where = s0
+                            break
+                if where is None:
+                    where = size
+                where_of[n_] = where
+                placed.append((where, nb, init, a, b))
+                size = max(size, where + nb)
+            return size, where_of
+        # first fit is order dependent: try a few orders (as given; persistent first then by birth; by size) and
+        # keep the tightest packing
+        idx = list(range(len(req)))
+        orders = [idx,
+                  sorted(idx, key=lambda n_: (req[n_][2] > -INF, req[n_][2], -len(req[n_][0]))),
+                  sorted(idx, key=lambda n_: (req[n_][2] > -INF, -len(req[n_][0]), req[n_][2])),
+                  sorted(idx, key=lambda n_: (req[n_][2] > -INF, -(req[n_][3] - req[n_][2]), -len(req[n_][0])))]
+        size, where_of = min((pack(o) for o in orders), key=lambda r: r[0])
+        for n_, (blk, *_rest) in enumerate(req):
             for q, i in enumerate(blk):
-                pslot[i] = where + q
-            placed.append((where, nb, init, a, b))
-            size = max(size, where + nb)
+                pslot[i] = where_of[n_] + q
         return size
 
     def leaf(self, j):

@@ -152,10 +152,12 @@ def _replay_storage(tape, L, names):
     return checked
 
 
+@pytest.mark.parametrize("fine", [False, True], ids=["coarse", "fine"])
 @pytest.mark.parametrize("lanes", [1, 8])
-def test_shared_slots_never_hold_the_wrong_value_on_sls_traces(sls_spec, sls_tape_path, lanes):
+def test_shared_slots_never_hold_the_wrong_value_on_sls_traces(sls_spec, sls_tape_path, lanes, fine, monkeypatch):
     from tenscalc_amd.lowering import Lowering
     from oracle.tc_oracle import DeviceLoopOracle
+    monkeypatch.setattr(Lowering, "FINE_LIVES", fine)      # both life-time models (the finer one is opt-in)
     L = Lowering(sls_spec.tape, sls_spec.code, roll=True, lanes=lanes, share=sls_spec.defines)
     L0 = Lowering(sls_spec.tape, sls_spec.code, roll=True, lanes=lanes)
     assert L.nPriv < 0.9 * L0.nPriv                                   # sharing actually happens
@@ -190,7 +192,11 @@ def test_shared_slots_on_template_branches(native_built, tmp_path, kind, opt):
     tape = str(tmp_path / "p.tape")
     save_tape(spec.tape, tape)
     do = DeviceLoopOracle(tape, "shr_%s_%d" % (kind, OPTIONS.index(opt)), spec.defines)
-    L = Lowering(spec.tape, spec.code, roll=True, lanes=1, share=spec.defines)
+    Ls = []
+    for fine in (False, True):
+        Lowering.FINE_LIVES = fine
+        Ls.append(Lowering(spec.tape, spec.code, roll=True, lanes=1, share=spec.defines))
+    Lowering.FINE_LIVES = False
     c = spec.classname
     rs = np.random.RandomState(5)
     for trial in range(8):
@@ -201,4 +207,5 @@ def test_shared_slots_on_template_branches(native_built, tmp_path, kind, opt):
         do.set(c + "_set_A", A); do.set(c + "_set_b", b); do.set(c + "_set_x", x0)
         do.solve(1.0 if trial % 2 else 1e-2, 40 if trial != 3 else 3, -1, ae)
         names = [c + "_set_A", c + "_set_b", c + "_set_x"] + do.trace() + [c + "_getOutputs"]
-        assert _replay_storage(spec.tape, L, names) > 0
+        for L in Ls:
+            assert _replay_storage(spec.tape, L, names) > 0
