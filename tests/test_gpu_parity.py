@@ -289,7 +289,8 @@ def test_dcmotor_strict_bit_exact_vs_oracle(libs, tmp_path):
 
 def test_odd_sized_sls_both_lowerings(libs, tmp_path):
     """sls with N=37 rows (not a multiple of the 8 lanes: zero padding + masked tail terms in the
-    reductions) and n=5 unknowns: strict bit-exact, w8 within the stated tolerance."""
+    reductions) and n=5 unknowns: strict bit-exact, w8 within the stated tolerance; w8s = the hoisted tape with the
+    inputs streamed (the last row block of the prologue sweep is ragged: 37 = 4*8+5)."""
     import __graft_entry__ as g
     from tenscalc_amd.problems.sls import sls
     from tenscalc_amd.tapeio import save_tape
@@ -306,7 +307,7 @@ def test_odd_sized_sls_both_lowerings(libs, tmp_path):
     c = spec.classname
     ref, rst, rit = Oracle(tape).solve_batch({c + "_set_A": At.reshape(B, -1), c + "_set_b": b, c + "_set_x": x0},
                                              c + "_getOutputs", B, mu0=1.0, maxIter=30)
-    for tag, exact in (("sls37_strict", True), ("sls37_w8", False)):
+    for tag, exact in (("sls37_strict", True), ("sls37_w8", False), ("sls37_w8s", False)):
         obj = _load(libs[tag], B)
         obj.setP_A(At); obj.setP_b(b); obj.setV_x(x0)
         st, it, _ = obj.solve(**SOLVE_ARGS)
