@@ -120,3 +120,64 @@ def test_hoisted_solver_agrees_with_the_reference_tape(native_built, tmp_path, k
     ok = s0 == 0
     assert ok.mean() > 0.9
     assert np.abs(o0[ok] - o1[ok]).max() <= 1e-4 and np.quantile(np.abs(o0[ok] - o1[ok]).max(axis=1), 0.8) <= 1e-7
+
+
+def _random_expr(rs, slow, fast, depth):
+    """random scalar/vector/matrix expression over slow (parameter) and fast variables built from plus, tprod
+    (matrix-vector, matrix-matrix, inner, outer, Hadamard) and norm2"""
+    leaves = slow + fast
+    if depth == 0:
+        return leaves[rs.randint(len(leaves))]
+    a = _random_expr(rs, slow, fast, depth - 1)
+    b = _random_expr(rs, slow, fast, depth - 1)
+    for _ in range(8):
+        kind = rs.randint(6)
+        try:
+            if kind == 0 and a.size == b.size:
+                return tc.plus([a, b], [1, -1 if rs.rand() < .5 else 1])
+            if kind == 1 and a.ndim == 2 and b.ndim >= 1 and a.size[1] == b.size[0]:
+                return a * b
+            if kind == 2 and a.ndim == 2 and b.ndim == 1 and a.size[0] == b.size[0]:
+                return tc.tprod(a, (-1, 1), b, (-1,))                    # a' b
+            if kind == 3 and a.size == b.size and a.ndim >= 1:
+                return tc.times(a, b)
+            if kind == 4 and a.ndim == 1 and b.ndim == 1 and a.size == b.size:
+                return tc.tprod(a, (-1,), b, (-1,)) * a                   # (a.b) a
+            if kind == 5 and a.ndim >= 1:
+                return tc.norm2(a) * b if rs.rand() < .5 else tc.plus([tc.norm2(a) * b, b], [1, 1])
+        except ValueError:
+            pass
+        a, b = b, a
+    return tc.plus([a, a], [1, 1]) if rs.rand() < .5 else a
+
+
+@pytest.mark.parametrize("seed", range(12))
+def test_random_expressions_evaluate_the_same_after_rewriting(tape_oracle, seed):
+    """index bookkeeping of R1-R3 on random expression DAGs: value (and value of the gradient with respect to a
+    fast variable, where it exists) unchanged to rounding"""
+    rs = np.random.RandomState(100 + seed)
+    n, m = 4, 3
+    P = tc.Tvariable("P", (n, m)); Q = tc.Tvariable("Q", (m, m)); c = tc.Tvariable("c", (m,)); d = tc.Tvariable("d", (n,))
+    x = tc.Tvariable("x", (m,)); y = tc.Tvariable("y", (n,))
+    slow, fast = [P, Q, c, d], [x, y]
+    vals = [rs.rand(n, m), rs.rand(m, m), rs.rand(m), rs.rand(n), rs.rand(m), rs.rand(n)]
+    outs, nrew = {}, 0
+    for k in range(6):
+        e = _random_expr(rs, slow, fast, 3)
+        h = Hoister(slow)
+        e2 = h.rewrite(e)
+        nrew += len(h.log)
+        outs[f"e{k}"], outs[f"r{k}"] = e, e2
+        if e.size == ():
+            try:
+                g_ = tc.gradient(e, x)
+            except NotImplementedError:
+                continue
+            outs[f"g{k}"], outs[f"s{k}"] = g_, Hoister(slow).rewrite(g_)
+    got, _, _ = run(tape_oracle, slow + fast, vals, outs)
+    for k in range(6):
+        scale = max(1.0, float(np.abs(got[f"e{k}"]).max()))
+        np.testing.assert_allclose(got[f"r{k}"], got[f"e{k}"], rtol=1e-11, atol=1e-11 * scale, err_msg=f"e{k}")
+        if f"g{k}" in got:
+            scale = max(1.0, float(np.abs(got[f"g{k}"]).max()))
+            np.testing.assert_allclose(got[f"s{k}"], got[f"g{k}"], rtol=1e-11, atol=1e-11 * scale, err_msg=f"g{k}")
