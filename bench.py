@@ -38,7 +38,7 @@ def main():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--batch", type=int, default=65536, help="instances per GPU")
-    ap.add_argument("--variant", default=os.environ.get("TC_BENCH_VARIANT", "w8s"), choices=["strict", "fast", "w8", "w8h", "regs", "regsl", "w8s"],
+    ap.add_argument("--variant", default=os.environ.get("TC_BENCH_VARIANT", "w8s"), choices=["strict", "fast", "w8", "w8h", "regs", "regsl", "w8s", "w8x"],
                     help="strict: 1 thread/instance, -ffp-contract=off, the reference tape, bit-exact vs the oracle; fast: "
                          "same with FMA; w8: 8 lanes/instance wave-cooperative lowering of the reference tape; w8s "
                          "(default): the same lowering of the hoisted tape (parameter-only contractions first, "

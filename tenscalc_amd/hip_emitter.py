@@ -76,6 +76,7 @@ class Printer:
         self._fused = {}            # sum instruction id -> name of its accumulated value in this group
         self._fused_d = {}          # distributed reduction id -> (name of its per-lane partial sum, scale)
         self._prefused = {}         # ... already accumulated by a sweep shared by several groups (kernel prologue)
+        self._staged = {}           # exact lowering: distributed reduction id -> text of its (replicated) value
         # store->load forwarding inside a group (lanes>1): a value just written to LDS by this lane is
         # read back from the register that holds it -- a replicated value by every later statement of
         # the group, element c_ of a lane-split family by the aligned member c_ of a later family --
@@ -83,6 +84,13 @@ class Printer:
         # other lanes of the instance write other slots)
         self.forward = False
         self.branch_free_tails = True
+        # exact=True (lanes>1): the wave-cooperative lowering keeps the reference's arithmetic bit for bit --
+        # sums over lane-distributed operands are accumulated in the reference's term order (staged through LDS:
+        # exact_dsweeps), sums over replicated operands are not lane-split, min/max/clp butterflies fall back to
+        # the reference's sequential chain when the result is NaN or a zero (whose sign is order dependent)
+        self.exact = False
+        self.stg_base = self.res_base = 0      # first LDS slot of the staging buffers / of the staged results
+        self.stg_nbuf = 2
         self._rv = {}               # slot -> index into c.rv[]: register copy that outlives the group (setup_rcache)
         self._fw_rep = {}           # slot -> name of the register copy (replicated values)
         self._fw_fam = {}           # (first slot, slot stride) -> (name prefix of per-block copies, members)
@@ -128,7 +136,7 @@ class Printer:
             return f"c.dX{vec[1]}[{vec[2] * d['K'] + k}]"
         return f"c.dF{vec[1]}[{k}]"
 
-    def _reduction_terms(self, t, symbolic=False):
+    def _reduction_terms(self, t, symbolic=False, guard=True):
         """per-lane terms (one per block of P rows) of a sum over aligned distributed operands, and the
         power-of-two literal factor taken out of the sum"""
         L = self.L
@@ -142,6 +150,8 @@ class Printer:
         skip = set()
         for p, (kind, v) in enumerate(facs):
             lf = t.kids[p]
+            if self.exact:
+                break       # (2*a)*b and 2*(a*b) differ once a*b is subnormal: keep the reference's factors
             if kind == "r" and lf.kind == "lit" and lf.val != 0 and math.frexp(abs(lf.val))[0] == 0.5:
                 scale *= lf.val
                 skip.add(p)
@@ -158,7 +168,7 @@ class Printer:
                 else:
                     fs.append(self.leaf_text(t.kids[p]))
             tk = f"{fs[0]}*{fs[0]}" if t.typ == I.I_plus_sqr else "*".join(fs)
-            if not isinstance(k, str) and (k + 1) * P_ > ns:
+            if guard and not isinstance(k, str) and (k + 1) * P_ > ns:
                 tk = f"(({k * P_}+c.lane<{ns})?({tk}):0.0)"
             terms.append(tk)
         if symbolic:
@@ -167,6 +177,10 @@ class Printer:
 
     def reduction(self, t):
         """sum over aligned distributed operands: per-lane partial sum + butterfly all-reduce"""
+        if t.ins in self._staged:
+            return self._staged[t.ins]
+        if self.exact:
+            raise AssertionError("exact lowering: distributed reduction outside a staged sweep")
         if t.ins in self._fused_d:
             e, scale = self._fused_d[t.ins]
             return f"tc_allreduce({e})" if scale == 1.0 else f"({_lit(scale)}*tc_allreduce({e}))"
@@ -239,6 +253,87 @@ class Printer:
             self._fused_d[t.ins] = (f"fd{t.ins}", scale)
         return w
 
+    def exact_dsweeps(self, g):
+        """exact lowering (lanes>1): every sum of group g over lane-distributed operands, accumulated in the
+        REFERENCE's term order (instructionsTableUTHash.c:987-1061: terms left to right, a new "m[r]+=" chain every
+        MAX_TERMS_PERLINE factors), so the value is the one a single thread would compute, bit for bit.
+
+        A butterfly all-reduce reassociates; a running sum handed from lane to lane would leave 7 of the 8 lanes
+        idle (registers cannot be indexed per lane, so the lanes cannot work on different columns of a skewed
+        pipeline).  Instead the sums are TRANSPOSED through LDS: the reductions of one shape are the columns, the
+        terms the rows.  Per block of P rows every lane computes the products of ITS row for P columns and writes
+        them to a staging buffer (P x P doubles, row stride P+1: conflict-free both ways); then lane c adds the P
+        staged terms of column c to its running chain, in order.  All P lanes stay busy (P columns in flight), each
+        product is computed once, each sum is a sequential chain in one lane.  Two staging buffers alternate so the
+        LDS round trip of one block overlaps the products of the next.  The totals end up in the staging area
+        (dead by then), one slot per reduction, where the group's statements read them as replicated values."""
+        L = self.L
+        self._staged = {}
+        if not self.exact or L.P == 1:
+            return ""
+        nodes = []
+        for g_ in (g if isinstance(g, (list, tuple)) else [g]):
+            for u in L.units[g_ - 1]:
+                if isinstance(u, (int, np.integer)):
+                    self._dreduce_nodes(L.tree(int(u)), nodes)
+        if not nodes:
+            return ""
+        P_ = L.P
+        RS = P_ + 1                                  # row stride of a staged column
+        nbuf = self.stg_nbuf
+        byshape = {}
+        for t in nodes:
+            nf, ns, facs = L.dreduce[t.ins]
+            byshape.setdefault((t.typ, nf, ns), []).append(t)
+        if sum(-(-len(v) // P_) * P_ for v in byshape.values()) > nbuf * P_ * RS:
+            raise NotImplementedError("exact lowering: more distributed reductions in one group than staging slots")
+        w = ["  { // sums over lane-distributed operands in the reference's term order, transposed through LDS\n"]
+        rnd = 0
+        res = 0
+        tails = []
+        for sh, (key, lst) in enumerate(byshape.items()):
+            typ, nf, ns = key
+            chunks = self._chunks(typ, nf, ns)
+            start_of = {a: ci for ci, (a, _) in enumerate(chunks)}
+            K = -(-ns // P_)
+            R = len(lst)
+            per = [self._reduction_terms(t, guard=False)[0] for t in lst]
+            nq = -(-R // P_)
+            for q in range(nq):
+                nm = f"s{sh}_{q}"
+                w.append(f"    double {nm}l_ = 0.0, {nm}t_ = 0.0;\n")
+                ncol = min(P_, R - q * P_)
+                for k in range(K):
+                    buf = self.stg_base + (rnd % nbuf) * P_ * RS
+                    rnd += 1
+                    for cc in range(ncol):
+                        w.append(f"    MM({buf + cc * RS}+lane) = {per[q * P_ + cc][k]};\n")
+                    w.append("    __builtin_amdgcn_wave_barrier();\n")
+                    for r in range(min(P_, ns - k * P_)):
+                        row = k * P_ + r
+                        v = f"MM({buf + r}+lane*{RS})"
+                        ci = start_of.get(row)
+                        if ci is None:
+                            w.append(f"    {nm}l_ = {nm}l_ + {v};\n")
+                        else:
+                            if ci == 1:
+                                w.append(f"    {nm}t_ = {nm}l_;\n")
+                            elif ci > 1:
+                                w.append(f"    {nm}t_ = {nm}t_ + {nm}l_;\n")
+                            w.append(f"    {nm}l_ = {v};\n")
+                    if nbuf == 1:
+                        w.append("    __builtin_amdgcn_wave_barrier();\n")
+                tot = f"{nm}l_" if len(chunks) == 1 else f"({nm}t_ + {nm}l_)"
+                guard = "" if ncol == P_ else f"if (lane < {ncol}) "
+                tails.append(f"    {guard}MM({self.stg_base + res}+lane) = {tot};\n")
+                for cc in range(ncol):
+                    self._staged[lst[q * P_ + cc].ins] = f"MM({self.stg_base + res + cc})"
+                res += P_
+        w.append("    __builtin_amdgcn_wave_barrier();\n")
+        w += tails
+        w.append("    __builtin_amdgcn_wave_barrier();\n  }\n")
+        return "".join(w)
+
     def dfamily_body(self, f):
         L = self.L
         K = -(-f.n // L.P)
@@ -300,6 +395,8 @@ class Printer:
         if L.P <= 1 or t.typ not in self._LANE_RED:
             return None
         kind, w = self._LANE_RED[t.typ]
+        if self.exact and (kind == "add" or t.typ in (I.I_min0, I.I_max0)):
+            return None         # a lane-split sum reassociates; min0/max0 start from a zero (see below)
         if t.typ == I.I_sumprod:
             w = int(t.par[0])
         n = len(t.kids) // w
@@ -347,6 +444,8 @@ class Printer:
         if not runs or sum(k1 - k0 for k0, k1, _ in runs) < L.P:
             return None
         init = {I.I_min: "DBL_MAX", I.I_max: "-DBL_MAX", I.I_clp: "DBL_MAX"}.get(ty, "0.0")
+        if self.exact:
+            init = {I.I_min: "__builtin_inf()", I.I_max: "(-__builtin_inf())", I.I_clp: "DBL_MAX"}.get(ty, "0.0")
         red = {"add": "tc_allreduce", "min": "tc_allreduce_min", "max": "tc_allreduce_max"}[kind]
         body = f"({{ double a_ = {init};"
         for k0, k1, cols in runs:
@@ -360,6 +459,16 @@ class Printer:
                 kid = t.kids[k * w + p]
                 cols.append(self.leaf_text(kid) if isinstance(kid, Leaf) else "(" + self.expr(kid) + ")")
             body += " " + step(cols)
+        if self.exact:
+            # min/max of the same operands is order independent EXCEPT where the reference's chain
+            # "if (acc > x) acc = x" depends on position: a NaN operand (kept only in first position, skipped
+            # elsewhere) and equal zeros of opposite sign (the first one stays).  The butterfly propagates NaN, so
+            # both cases show in the result and take the reference's own sequential chain (cold path; every lane
+            # of the instance holds the same a_, so the instance's lanes branch together)
+            r = []
+            for kid in t.kids:
+                r.append(self.leaf_text(kid) if isinstance(kid, Leaf) else "(" + self.expr(kid) + ")")
+            body += " if (__builtin_expect(a_ != a_ || a_ == 0.0, 0)) { a_ = " + self.op_text(ty, t.par, r) + "; }"
         body += " a_; })"
         if ty == I.I_sum and t.par[0] < 0:
             body = "-" + body
@@ -615,7 +724,7 @@ class Printer:
     def group_body(self, g):
         """HIP statements of dependency group g (1-based)"""
         L = self.L
-        out = [self.fused_sweeps(g), self.fused_dsweeps(g)]
+        out = [self.fused_sweeps(g), self.fused_dsweeps(g), self.exact_dsweeps(g)]
         self._rc = {}
         self._fw_rep, self._fw_fam = {}, {}
         self._pending = []          # slot ranges written by lane-split stores since the last wave barrier
@@ -821,8 +930,12 @@ def _mask(groups):
 def emit_class(spec, fp_contract="fast", block=64, stats=False, roll=True, min_waves=0, lanes=1,
                recip=False, fast_div=False, inline_max=0, reg_budget=150, scratch="auto", body="code",
                waves=1, fuse=False, static_clean=False, forward=False, rcache=0, lds_state=0, share=False,
-               branch_free_tails=True):
+               branch_free_tails=True, exact=False, stg_nbuf=2):
     """Return the HIP source text of the solver class.
+
+    exact=True (lanes>1, fp_contract='off', no recip/fast_div): the wave-cooperative lowering with the
+    reference's arithmetic kept bit for bit (Printer.exact_dsweeps / lane_reduction): same outputs, status and
+    iteration counts as the one-thread-per-instance `strict` lowering and the CPU oracle.
 
     branch_free_tails=False: ragged tails of lane-split families keep their predicate; saves the spare LDS slot
     and the tail pad the branch-free form needs (sls/w8s: exactly the difference between 6 and 7 wavefronts per CU).
@@ -865,6 +978,10 @@ def emit_class(spec, fp_contract="fast", block=64, stats=False, roll=True, min_w
         raise ValueError("block must be a multiple of lanes")
     P = Printer(L, roll=roll, recip=recip, fuse=fuse)
     P.forward = bool(forward) and lanes > 1
+    P.exact = bool(exact) and lanes > 1
+    if P.exact and (recip or fast_div or fuse or fp_contract != "off"):
+        raise ValueError("exact=True needs fp_contract='off' and no recip/fast_div/fuse")
+    P.stg_nbuf = int(stg_nbuf)
     P.branch_free_tails = bool(branch_free_tails)
     nrv = P.setup_rcache(rcache) if (P.forward and not interp) else 0
     if nrv:
@@ -897,6 +1014,9 @@ def emit_class(spec, fp_contract="fast", block=64, stats=False, roll=True, min_w
         consts = isch.constant_rows(T, L)[0]
     dummy = 1 if (forward and lanes > 1 and branch_free_tails) else 0
     nmp = max(1, L.nPriv) + dummy                                  # + TC_DUMMY
+    if P.exact:                                                    # staging buffers of the ordered sums
+        P.stg_base = nmp
+        nmp += P.stg_nbuf * lanes * (lanes + 1)
     nmp += int(os.environ.get("TC_LDS_PAD_SLOTS", "0"))      # occupancy experiments only
     # per-instance stride = 8 mod 16 doubles: the 4 instances of a half-wave start 16 banks apart either way
     # (8 mod 32: 0,16,32,48; 24 mod 32: 0,48,32,16), so broadcast reads and 8-lane reads of consecutive
@@ -1386,7 +1506,7 @@ def build_class(spec, fp_contract="fast", arch="gfx950", opt="-O3", block=64, fo
                 outdir=None, stats=False, tag=None, extra_flags=(), roll=True, min_waves=0, lanes=1,
                 recip=False, fast_div=False, inline_max=0, reg_budget=150, scratch="auto", body="code",
                 waves=1, fuse=False, static_clean=False, forward=False, rcache=0, lds_state=0, share=False,
-                branch_free_tails=True):
+                branch_free_tails=True, exact=False, stg_nbuf=2):
     """Emit <cls>.hip (+ <cls>.h, <cls>.tape) and compile lib<cls>.so with hipcc for gfx950.
     Mirrors the createGateway/compile step of cmex2optimizeCS.m:403-417."""
     from .tapeio import save_tape
@@ -1398,7 +1518,7 @@ def build_class(spec, fp_contract="fast", arch="gfx950", opt="-O3", block=64, fo
                         min_waves=min_waves, lanes=lanes, recip=recip, fast_div=fast_div, inline_max=inline_max,
                         reg_budget=reg_budget, scratch=scratch, body=body, waves=waves, fuse=fuse,
                         static_clean=static_clean, forward=forward, rcache=rcache, lds_state=lds_state,
-                        share=share, branch_free_tails=branch_free_tails)
+                        share=share, branch_free_tails=branch_free_tails, exact=exact, stg_nbuf=stg_nbuf)
     hip = os.path.join(outdir, f"{cls}{suffix}.hip")
     so = os.path.join(outdir, f"lib{cls}{suffix}.so")
     flags = [opt, f"--offload-arch={arch}", "-fPIC", "-shared", "-std=c++17",
