@@ -95,7 +95,8 @@ int tc_probe(tc_solver_t *h, const char *getName, double mu0, const double *addE
 int64_t tc_probe_numel(const char *getName);
 
 /* ---- diagnostics of builds made with stats=True (TC_STATS): rows [0,G) wall cycles spent in
- * dependency group g, [G,2G) evaluation counts, 2G total kernel cycles, 2G+1 getMinF_s__ trials;
+ * dependency group g, [G,2G) evaluation counts, 2G total kernel cycles, 2G+1 getMinF_s__ trials,
+ * [2G+2,2G+10) wall cycles per phase of the Newton loop (csrc/ipm_newton.hip.inc: TC_PH);
  * out is [tc_stats_rows()][B].  All zero for ordinary builds. */
 int64_t tc_stats_rows(void);
 int tc_get_stats(tc_solver_t *h, double *out);

@@ -12,7 +12,7 @@ from tenscalc_amd.problems.sls import SOLVE_ARGS, sls
 from tenscalc_amd.runtime import LAYOUT_BATCH_MINOR, HipSolver
 
 var = sys.argv[1] if len(sys.argv) > 1 else "w8"
-spec = sls(folder=g.GENERATED)
+spec = g.sls_spec(var)
 kw = dict(g.VARIANT_KW[var])
 kw["tag"] = var + "_stats"
 so = spec.build(stats=True, **kw)
@@ -28,9 +28,11 @@ obj.synchronize()
 for _ in range(3):
     st, it, tm = obj.solve(**SOLVE_ARGS)
 s = obj.stats()
-G = (s.shape[0] - 2) // 2
+G = (s.shape[0] - 10) // 2
 tot = s[2 * G].mean()
 print(f"{var}: kernel {tm*1e3:.3f} ms, mean cycles/instance-thread {tot:.0f}, iters {it.mean():.2f}, minF trials {s[2*G+1].mean():.1f}")
+print("phases [init, exit tests, curvature+direction error, alpha bounds, line search, update, mu, -] cycles per solve:",
+      " ".join("%.0f" % s[2 * G + 2 + k].mean() for k in range(8)))
 T = spec.tape
 rows = []
 for k in range(G):

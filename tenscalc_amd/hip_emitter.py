@@ -90,7 +90,7 @@ class Printer:
         # the reference's sequential chain when the result is NaN or a zero (whose sign is order dependent)
         self.exact = False
         self.stg_base = self.res_base = 0      # first LDS slot of the staging buffers / of the staged results
-        self.stg_nbuf = 2
+        self.stg_blocks = 1                    # row blocks (of P terms) staged per LDS round trip
         self._rv = {}               # slot -> index into c.rv[]: register copy that outlives the group (setup_rcache)
         self._fw_rep = {}           # slot -> name of the register copy (replicated values)
         self._fw_fam = {}           # (first slot, slot stride) -> (name prefix of per-block copies, members)
@@ -264,8 +264,8 @@ class Printer:
         terms the rows.  Per block of P rows every lane computes the products of ITS row for P columns and writes
         them to a staging buffer (P x P doubles, row stride P+1: conflict-free both ways); then lane c adds the P
         staged terms of column c to its running chain, in order.  All P lanes stay busy (P columns in flight), each
-        product is computed once, each sum is a sequential chain in one lane.  Two staging buffers alternate so the
-        LDS round trip of one block overlaps the products of the next.  The totals end up in the staging area
+        product is computed once, each sum is a sequential chain in one lane.  Several row blocks are staged per
+        round (as many as the LDS budget allows) so that a round costs one LDS round trip.  The totals end up in the staging area
         (dead by then), one slot per reduction, where the group's statements read them as replicated values."""
         L = self.L
         self._staged = {}
@@ -280,15 +280,14 @@ class Printer:
             return ""
         P_ = L.P
         RS = P_ + 1                                  # row stride of a staged column
-        nbuf = self.stg_nbuf
+        NB = self.stg_blocks                         # row blocks staged per round
         byshape = {}
         for t in nodes:
             nf, ns, facs = L.dreduce[t.ins]
             byshape.setdefault((t.typ, nf, ns), []).append(t)
-        if sum(-(-len(v) // P_) * P_ for v in byshape.values()) > nbuf * P_ * RS:
+        if sum(-(-len(v) // P_) * P_ for v in byshape.values()) > NB * P_ * RS:
             raise NotImplementedError("exact lowering: more distributed reductions in one group than staging slots")
         w = ["  { // sums over lane-distributed operands in the reference's term order, transposed through LDS\n"]
-        rnd = 0
         res = 0
         tails = []
         for sh, (key, lst) in enumerate(byshape.items()):
@@ -303,33 +302,37 @@ class Printer:
                 nm = f"s{sh}_{q}"
                 w.append(f"    double {nm}l_ = 0.0, {nm}t_ = 0.0;\n")
                 ncol = min(P_, R - q * P_)
-                for k in range(K):
-                    buf = self.stg_base + (rnd % nbuf) * P_ * RS
-                    rnd += 1
-                    for cc in range(ncol):
-                        w.append(f"    MM({buf + cc * RS}+lane) = {per[q * P_ + cc][k]};\n")
+                for k0 in range(0, K, NB):
+                    blocks = list(range(k0, min(K, k0 + NB)))
+                    # every lane: the products of its row of each block, for the columns of this column block
+                    for bi, k in enumerate(blocks):
+                        for cc in range(ncol):
+                            w.append(f"    MM({self.stg_base + bi * P_ * RS + cc * RS}+lane) = {per[q * P_ + cc][k]};\n")
                     w.append("    __builtin_amdgcn_wave_barrier();\n")
-                    for r in range(min(P_, ns - k * P_)):
-                        row = k * P_ + r
-                        v = f"MM({buf + r}+lane*{RS})"
+                    # lane c: the staged terms of column c, all loads first (one LDS round trip per round), then
+                    # the chain of additions in row order
+                    rows = [(bi, r) for bi, k in enumerate(blocks) for r in range(min(P_, ns - k * P_))]
+                    w.append("    { const double " + ", ".join(
+                        f"v{bi}_{r} = MM({self.stg_base + bi * P_ * RS + r}+lane*{RS})" for bi, r in rows) + ";\n")
+                    for bi, r in rows:
+                        row = blocks[bi] * P_ + r
+                        v = f"v{bi}_{r}"
                         ci = start_of.get(row)
                         if ci is None:
-                            w.append(f"    {nm}l_ = {nm}l_ + {v};\n")
+                            w.append(f"      {nm}l_ = {nm}l_ + {v};\n")
                         else:
                             if ci == 1:
-                                w.append(f"    {nm}t_ = {nm}l_;\n")
+                                w.append(f"      {nm}t_ = {nm}l_;\n")
                             elif ci > 1:
-                                w.append(f"    {nm}t_ = {nm}t_ + {nm}l_;\n")
-                            w.append(f"    {nm}l_ = {v};\n")
-                    if nbuf == 1:
-                        w.append("    __builtin_amdgcn_wave_barrier();\n")
+                                w.append(f"      {nm}t_ = {nm}t_ + {nm}l_;\n")
+                            w.append(f"      {nm}l_ = {v};\n")
+                    w.append("    }\n    __builtin_amdgcn_wave_barrier();\n")
                 tot = f"{nm}l_" if len(chunks) == 1 else f"({nm}t_ + {nm}l_)"
                 guard = "" if ncol == P_ else f"if (lane < {ncol}) "
                 tails.append(f"    {guard}MM({self.stg_base + res}+lane) = {tot};\n")
                 for cc in range(ncol):
                     self._staged[lst[q * P_ + cc].ins] = f"MM({self.stg_base + res + cc})"
                 res += P_
-        w.append("    __builtin_amdgcn_wave_barrier();\n")
         w += tails
         w.append("    __builtin_amdgcn_wave_barrier();\n  }\n")
         return "".join(w)
@@ -930,7 +933,7 @@ def _mask(groups):
 def emit_class(spec, fp_contract="fast", block=64, stats=False, roll=True, min_waves=0, lanes=1,
                recip=False, fast_div=False, inline_max=0, reg_budget=150, scratch="auto", body="code",
                waves=1, fuse=False, static_clean=False, forward=False, rcache=0, lds_state=0, share=False,
-               branch_free_tails=True, exact=False, stg_nbuf=2):
+               branch_free_tails=True, exact=False, stg_blocks=0):
     """Return the HIP source text of the solver class.
 
     exact=True (lanes>1, fp_contract='off', no recip/fast_div): the wave-cooperative lowering with the
@@ -981,7 +984,6 @@ def emit_class(spec, fp_contract="fast", block=64, stats=False, roll=True, min_w
     P.exact = bool(exact) and lanes > 1
     if P.exact and (recip or fast_div or fuse or fp_contract != "off"):
         raise ValueError("exact=True needs fp_contract='off' and no recip/fast_div/fuse")
-    P.stg_nbuf = int(stg_nbuf)
     P.branch_free_tails = bool(branch_free_tails)
     nrv = P.setup_rcache(rcache) if (P.forward and not interp) else 0
     if nrv:
@@ -1014,9 +1016,20 @@ def emit_class(spec, fp_contract="fast", block=64, stats=False, roll=True, min_w
         consts = isch.constant_rows(T, L)[0]
     dummy = 1 if (forward and lanes > 1 and branch_free_tails) else 0
     nmp = max(1, L.nPriv) + dummy                                  # + TC_DUMMY
-    if P.exact:                                                    # staging buffers of the ordered sums
+    if P.exact:                                                    # staging area of the ordered sums
+        # stg_blocks=0: as many row blocks per round as fit while 4 wavefronts per CU (one per SIMD: the
+        # distributed inputs are register resident) still share the 160 KB of LDS
         P.stg_base = nmp
-        nmp += P.stg_nbuf * lanes * (lanes + 1)
+        per_blk = lanes * (lanes + 1)
+        kmax = max([-(-v[1] // lanes) for v in L.dreduce.values()], default=1)
+        room = (163840 // 4 // (block // lanes) // 8 - 8 - nmp) // per_blk
+        P.stg_blocks = int(stg_blocks) if stg_blocks else max(1, min(kmax, room))
+        rmax = {}
+        for i_, v in L.dreduce.items():
+            rmax[int(T.group[i_])] = rmax.get(int(T.group[i_]), 0) + 1
+        while P.stg_blocks * per_blk < max([-(-r // lanes) * lanes for r in rmax.values()], default=0):
+            P.stg_blocks += 1                                      # the totals of a group's sums land there too
+        nmp += P.stg_blocks * per_blk
     nmp += int(os.environ.get("TC_LDS_PAD_SLOTS", "0"))      # occupancy experiments only
     # per-instance stride = 8 mod 16 doubles: the 4 instances of a half-wave start 16 banks apart either way
     # (8 mod 32: 0,16,32,48; 24 mod 32: 0,48,32,16), so broadcast reads and 8-lane reads of consecutive
@@ -1063,7 +1076,7 @@ def emit_class(spec, fp_contract="fast", block=64, stats=False, roll=True, min_w
              "struct TcCtx {\n  tc_mem m;\n  tc_lds ls;\n  tc_glob S;\n  tc_glob Sd;\n  long B, sdB;\n  int lane;\n"
              "  const __attribute__((address_space(1))) char *Sdb;\n  unsigned sdo8, sdB8;\n"
              "  unsigned long long st[TC_NSTW];\n" + (f"  double rv[{nrv}];\n" if nrv else "") + dmembers +
-             "#ifdef TC_STATS\n  int nMinF;\n  long long cyc[TC_NGROUPS];\n  int cnt[TC_NGROUPS];\n#endif\n};\n"
+             "#ifdef TC_STATS\n  int nMinF;\n  long long cyc[TC_NGROUPS];\n  int cnt[TC_NGROUPS];\n  long long ph[8], tph;\n#endif\n};\n"
              # input reads are clamped to the input block: every index the emitter prints is in range (constants
              # fold away), the clamp is the backstop for a lane of a split loop that should have been masked
              "#define SX(k) (S[(long)((k) < TC_NEXT ? (k) : (TC_NEXT > 0 ? TC_NEXT - 1 : 0)) * B])\n"
@@ -1297,7 +1310,8 @@ def emit_class(spec, fp_contract="fast", block=64, stats=False, roll=True, min_w
                 "  c.lane = (int)(t_ % TC_P);\n  c.S = (tc_glob)(S + tid);\n  c.B = B;\n"
                 "  for (int k = 0; k < TC_NSTW; k++) c.st[k] = 0;\n"
                 "#ifdef TC_STATS\n  c.nMinF = 0;\n  for (int k = 0; k < TC_NGROUPS; k++) { c.cyc[k] = 0; c.cnt[k] = 0; }\n"
-                "  const long long tstart_ = clock64();\n#endif\n")
+                "  for (int k = 0; k < 8; k++) c.ph[k] = 0;\n"
+                "  const long long tstart_ = clock64();\n  c.tph = tstart_;\n#endif\n")
     prologue += ("  c.Sd = (tc_glob)(Sd + tid * TC_P + c.lane);\n  c.sdB = B * TC_P;\n"
                  "  c.Sdb = (const __attribute__((address_space(1))) char *)Sd;\n"
                  "  c.sdo8 = (unsigned)((tid * TC_P + c.lane) * 8);\n  c.sdB8 = (unsigned)(B * TC_P * 8);\n")
@@ -1354,7 +1368,8 @@ def emit_class(spec, fp_contract="fast", block=64, stats=False, roll=True, min_w
              "#ifdef TC_STATS\n  if (dbg) {\n    for (int k = 0; k < TC_NGROUPS; k++) {\n"
              "      dbg[(long)k * B + tid] = (double)c.cyc[k];\n      dbg[(long)(TC_NGROUPS + k) * B + tid] = (double)c.cnt[k];\n    }\n"
              "    dbg[(long)(2 * TC_NGROUPS) * B + tid] = (double)(clock64() - tstart_);\n"
-             "    dbg[(long)(2 * TC_NGROUPS + 1) * B + tid] = (double)c.nMinF;\n  }\n#endif\n}\n\n")
+             "    dbg[(long)(2 * TC_NGROUPS + 1) * B + tid] = (double)c.nMinF;\n"
+             "    for (int k = 0; k < 8; k++) dbg[(long)(2 * TC_NGROUPS + 2 + k) * B + tid] = (double)c.ph[k];\n  }\n#endif\n}\n\n")
     # probe kernel: init sequence then one get
     w.append("extern \"C\" __global__ void __launch_bounds__(TC_BLOCK)\n"
              "tc_probe_kernel(const double *__restrict__ S, const double *__restrict__ Sd, double *__restrict__ out,\n"
@@ -1506,7 +1521,7 @@ def build_class(spec, fp_contract="fast", arch="gfx950", opt="-O3", block=64, fo
                 outdir=None, stats=False, tag=None, extra_flags=(), roll=True, min_waves=0, lanes=1,
                 recip=False, fast_div=False, inline_max=0, reg_budget=150, scratch="auto", body="code",
                 waves=1, fuse=False, static_clean=False, forward=False, rcache=0, lds_state=0, share=False,
-                branch_free_tails=True, exact=False, stg_nbuf=2):
+                branch_free_tails=True, exact=False, stg_blocks=0):
     """Emit <cls>.hip (+ <cls>.h, <cls>.tape) and compile lib<cls>.so with hipcc for gfx950.
     Mirrors the createGateway/compile step of cmex2optimizeCS.m:403-417."""
     from .tapeio import save_tape
@@ -1518,7 +1533,7 @@ def build_class(spec, fp_contract="fast", arch="gfx950", opt="-O3", block=64, fo
                         min_waves=min_waves, lanes=lanes, recip=recip, fast_div=fast_div, inline_max=inline_max,
                         reg_budget=reg_budget, scratch=scratch, body=body, waves=waves, fuse=fuse,
                         static_clean=static_clean, forward=forward, rcache=rcache, lds_state=lds_state,
-                        share=share, branch_free_tails=branch_free_tails, exact=exact, stg_nbuf=stg_nbuf)
+                        share=share, branch_free_tails=branch_free_tails, exact=exact, stg_blocks=stg_blocks)
     hip = os.path.join(outdir, f"{cls}{suffix}.hip")
     so = os.path.join(outdir, f"lib{cls}{suffix}.so")
     flags = [opt, f"--offload-arch={arch}", "-fPIC", "-shared", "-std=c++17",

@@ -352,6 +352,28 @@ class Lowering:
             for j in list(e.get("src", [])) + [x for o in e.get("outputs", []) for x in o["ins"]]:
                 direct.setdefault(int(j), []).extend(ts)
 
+        # groups that use lane-distributed state are PUSHED (hip_emitter: re-evaluated, with their ancestors, by the
+        # set/copy that invalidates them), i.e. earlier than the first get that needs them: the life times
+        # computed from the gets do not hold for them, they keep storage of their own
+        if self.P > 1:
+            dgroups = {int(grp[i]) for i in list(self.dval) + list(self.dreduce) if int(grp[i]) > 0}
+            in_loop = set()
+            for e in list(T.gets) + list(T.copies):
+                if e["name"] in tl["time"]:
+                    in_loop |= set(e["parents"])
+            gdeps = {}
+            for i in range(1, T.n + 1):
+                if T.used[i] and grp[i] > 0:
+                    for j in self._opl[self._ost[i - 1]:self._ost[i]]:
+                        if grp[j] > 0 and grp[j] != grp[i]:
+                            gdeps.setdefault(int(grp[i]), set()).add(int(grp[j]))
+            todo = [g_ for g_ in dgroups if g_ in in_loop]
+            while todo:
+                g_ = todo.pop()
+                if g_ not in keep:
+                    keep.add(g_)
+                    todo += list(gdeps.get(g_, ()))
+
         # groups no entry point of the solver ever invalidates (they depend on the parameters only): evaluated
         # once, in the first pass; a value of theirs that only other such groups read is dead after that
         varying = set()
