@@ -32,19 +32,32 @@ class _DevArray:
                                              version=2, strides=None)
 
 
+def make_batch(B, rank, dev):
+    """the benchmark batch of rank `rank`: A [800][B] (column-major A of each instance), b [100][B], x0 [8][B],
+    structure-of-arrays on `dev` (the distributions of examples/sls.m:36-41); shared with
+    tests/test_gpu_parity.py, which checks the default variant bit for bit on instances of THIS batch"""
+    import torch
+    gen = torch.Generator(device=dev).manual_seed(1234 + rank)
+    A = torch.rand((800, B), generator=gen, device=dev, dtype=torch.float64)
+    b = torch.rand((100, B), generator=gen, device=dev, dtype=torch.float64)
+    x0 = .02 * torch.rand((8, B), generator=gen, device=dev, dtype=torch.float64)
+    return A, b, x0
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--batch", type=int, default=65536, help="instances per GPU")
-    ap.add_argument("--variant", default=os.environ.get("TC_BENCH_VARIANT", "w8s"), choices=["strict", "fast", "w8", "w8h", "regs", "regsl", "w8s", "w8x"],
-                    help="strict: 1 thread/instance, -ffp-contract=off, the reference tape, bit-exact vs the oracle; fast: "
-                         "same with FMA; w8: 8 lanes/instance wave-cooperative lowering of the reference tape; w8s "
-                         "(default): the same lowering of the hoisted tape (parameter-only contractions first, "
-                         "tenscalc_amd/hoist.py) with the inputs streamed instead of register-resident and LDS slots "
-                         "shared by life time: 6 wavefronts per CU instead of 4; w8h / regs / regsl: other lowerings of "
-                         "the hoisted tape (DESIGN.md 3.6)")
+    ap.add_argument("--variant", default=os.environ.get("TC_BENCH_VARIANT", "w8x"), choices=["strict", "fast", "w8", "w8h", "regs", "regsl", "w8s", "w8x"],
+                    help="w8x (default): 8 lanes/instance wave-cooperative lowering of the REFERENCE tape with the "
+                         "reference's arithmetic kept bit for bit (parity class bit-exact: status, iteration count and "
+                         "outputs identical to the cmex reference on every instance); strict: 1 thread/instance, "
+                         "-ffp-contract=off, bit-exact too; fast: same with FMA; w8: the wave-cooperative lowering with "
+                         "FMA, reassociated reductions and fast division; w8s: the same of the hoisted tape (parameter-only "
+                         "contractions first, tenscalc_amd/hoist.py), inputs streamed, LDS slots shared, 6 wavefronts per "
+                         "CU -- parity class solver-tolerance; w8h / regs / regsl: other lowerings of the hoisted tape")
     ap.add_argument("--cpu-sample", type=int, default=int(os.environ.get("TC_CPU_SAMPLE", "65536")))
     ap.add_argument("--no-cpu", action="store_true")
     args = ap.parse_args()
@@ -87,10 +100,7 @@ def main():
     so = spec.build(**kw)
 
     B = args.batch
-    gen = torch.Generator(device=dev).manual_seed(1234 + rank)
-    A = torch.rand((800, B), generator=gen, device=dev, dtype=torch.float64)      # [N*n][B] column-major A per instance
-    b = torch.rand((100, B), generator=gen, device=dev, dtype=torch.float64)
-    x0 = .02 * torch.rand((8, B), generator=gen, device=dev, dtype=torch.float64)
+    A, b, x0 = make_batch(B, rank, dev)
     obj = HipSolver(so, B=B, device=local)
     stream = torch.cuda.current_stream().cuda_stream
     for nm, t in (("A", A), ("b", b), ("x", x0)):
@@ -177,6 +187,7 @@ def main():
                                    "(BASELINE.json configs[1])" % B,
                        "batch_per_gpu": B, "mu0": SOLVE_ARGS["mu0"], "maxIter": SOLVE_ARGS["maxIter"],
                        "variant": args.variant,
+                       "parity_class": g.PARITY_CLASS.get(args.variant, "solver-tolerance"),
                        "tape": ("hoisted (parameter-only contractions first); results within the stated tolerance of the "
                                 "reference tape, tests/test_gpu_parity.py" if args.variant in g.HOISTED else "reference"),
                        "solved_fraction": solved_per_step / (B * world),

@@ -15,7 +15,9 @@ var = sys.argv[1] if len(sys.argv) > 1 else "w8"
 spec = g.sls_spec(var)
 kw = dict(g.VARIANT_KW[var])
 kw["tag"] = var + "_stats"
-so = spec.build(stats=True, **kw)
+mode = sys.argv[2] if len(sys.argv) > 2 else "all"
+kw["tag"] = var + "_stats" + ("p" if mode == "phases" else "")
+so = spec.build(stats=("phases" if mode == "phases" else True), **kw)
 B = 65536
 gen = torch.Generator(device="cuda").manual_seed(1234)
 A = torch.rand((800, B), generator=gen, device="cuda", dtype=torch.float64)

@@ -91,6 +91,7 @@ class Printer:
         self.exact = False
         self.stg_base = self.res_base = 0      # first LDS slot of the staging buffers / of the staged results
         self.stg_blocks = 1                    # row blocks (of P terms) staged per LDS round trip
+        self.stg_batch = 16                    # staged terms loaded back to back before their additions
         self._rv = {}               # slot -> index into c.rv[]: register copy that outlives the group (setup_rcache)
         self._fw_rep = {}           # slot -> name of the register copy (replicated values)
         self._fw_fam = {}           # (first slot, slot stride) -> (name prefix of per-block copies, members)
@@ -312,21 +313,27 @@ class Printer:
                     # lane c: the staged terms of column c, all loads first (one LDS round trip per round), then
                     # the chain of additions in row order
                     rows = [(bi, r) for bi, k in enumerate(blocks) for r in range(min(P_, ns - k * P_))]
-                    w.append("    { const double " + ", ".join(
-                        f"v{bi}_{r} = MM({self.stg_base + bi * P_ * RS + r}+lane*{RS})" for bi, r in rows) + ";\n")
-                    for bi, r in rows:
-                        row = blocks[bi] * P_ + r
-                        v = f"v{bi}_{r}"
-                        ci = start_of.get(row)
-                        if ci is None:
-                            w.append(f"      {nm}l_ = {nm}l_ + {v};\n")
-                        else:
-                            if ci == 1:
-                                w.append(f"      {nm}t_ = {nm}l_;\n")
-                            elif ci > 1:
-                                w.append(f"      {nm}t_ = {nm}t_ + {nm}l_;\n")
-                            w.append(f"      {nm}l_ = {v};\n")
-                    w.append("    }\n    __builtin_amdgcn_wave_barrier();\n")
+                    for r0 in range(0, len(rows), self.stg_batch):
+                        part = rows[r0:r0 + self.stg_batch]
+                        w.append("    { const double " + ", ".join(
+                            f"v{bi}_{r} = MM({self.stg_base + bi * P_ * RS + r}+lane*{RS})" for bi, r in part) + ";\n")
+                        # keep the loads together: left alone, the scheduler (minimising register pressure) pairs
+                        # every load with its addition and waits for each one in turn
+                        w.append("      __builtin_amdgcn_sched_barrier(0);\n")
+                        for bi, r in part:
+                            row = blocks[bi] * P_ + r
+                            v = f"v{bi}_{r}"
+                            ci = start_of.get(row)
+                            if ci is None:
+                                w.append(f"      {nm}l_ = {nm}l_ + {v};\n")
+                            else:
+                                if ci == 1:
+                                    w.append(f"      {nm}t_ = {nm}l_;\n")
+                                elif ci > 1:
+                                    w.append(f"      {nm}t_ = {nm}t_ + {nm}l_;\n")
+                                w.append(f"      {nm}l_ = {v};\n")
+                        w.append("    }\n")
+                    w.append("    __builtin_amdgcn_wave_barrier();\n")
                 tot = f"{nm}l_" if len(chunks) == 1 else f"({nm}t_ + {nm}l_)"
                 guard = "" if ncol == P_ else f"if (lane < {ncol}) "
                 tails.append(f"    {guard}MM({self.stg_base + res}+lane) = {tot};\n")
@@ -999,8 +1006,8 @@ def emit_class(spec, fp_contract="fast", block=64, stats=False, roll=True, min_w
              f"#define TC_G (TC_BLOCK / TC_P)\n#define TC_NDIST {L.nDist}\n")
     lb = f"__launch_bounds__(TC_BLOCK, {int(min_waves)})" if min_waves else "__launch_bounds__(TC_BLOCK)"
     w.append(f"#define TC_LAUNCH_BOUNDS {lb}\n")
-    if stats:
-        w.append("#define TC_STATS 1\n")
+    if stats:       # stats="phases": only the per-phase counters of the Newton loop (8 registers; the per-group
+        w.append("#define TC_STATS %d\n" % (2 if stats == "phases" else 1))     # arrays perturb register allocation)
     w.append("// solver configuration (reference: cmex2optimizeCS.m:303-331)\n")
     for k in ["nU", "nG", "nF", "scaleCost", "scaleInequalities", "scaleEqualities", "coupledAlphas",
               "setAddEye2Hessian", "adjustAddEye2Hessian", "useInertia", "delta", "skipAffine",
@@ -1136,7 +1143,7 @@ def emit_class(spec, fp_contract="fast", block=64, stats=False, roll=True, min_w
             w.append(f"}}\n#define TC_CALL_GRP{g} tc_grp{g}(c.m, c.S, c.B, c.lane)\n")
     w.append("\n// TC_EVAL: the group is certainly dirty here (loop_schedule.py): evaluate without testing the flag\n"
              "#define TC_EVAL(g) do { c.st[((g)-1)>>6] |= 1ull << (((g)-1)&63); TC_CALL_GRP##g; } while (0)\n")
-    w.append("\n#ifndef TC_STATS\n#define TC_NEED(g) do { if (!((c.st[((g)-1)>>6] >> (((g)-1)&63)) & 1ull)) { "
+    w.append("\n#if !defined(TC_STATS) || TC_STATS == 2\n#define TC_NEED(g) do { if (!((c.st[((g)-1)>>6] >> (((g)-1)&63)) & 1ull)) { "
              "c.st[((g)-1)>>6] |= 1ull << (((g)-1)&63); TC_CALL_GRP##g; } } while (0)\n"
              "#else  // diagnostic build: wall cycles (s_memtime) and call count per dependency group\n"
              "#define TC_NEED(g) do { if (!((c.st[((g)-1)>>6] >> (((g)-1)&63)) & 1ull)) { "

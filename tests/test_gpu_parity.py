@@ -2,13 +2,17 @@
 same seeded inputs, against the committed golden vectors, and -- at BASELINE's full batch --
 through size-independent properties.
 
-Tolerances.  `strict` build (-ffp-contract=off): the tape is evaluated in the reference's operand
-order with IEEE fp64 +,-,*,/ so every output must be BIT-IDENTICAL to the oracle, including
-status and iteration count.  `fast` build (FMA contraction on): not bit-identical; a Newton
-line-search decision can flip on a 1e-17 residue (see tests/test_oracle_sls.py), so the stated
-tolerance is the solver's own (desiredDualityGap=1e-5, gradTolerance=1e-4): same status, |iter difference| <= 2,
-|J-J_ref| <= 5e-5, |x-x_ref| <= 5e-5, box-KKT residual <= 1e-4, and -- the north-star criterion -- KKT
-residual within 1e-10 of the oracle's on every instance where no line-search branch flipped.
+Parity classes (__graft_entry__.PARITY_CLASS).
+`bit-exact` -- `strict` (one thread per instance) and `w8x` (8 lanes per instance, bench.py's default): the tape
+is evaluated in the reference's operand order with IEEE fp64 +,-,*,/ (no FMA, ordered sums), so every output must be
+BIT-IDENTICAL to the oracle, including status and iteration count, on every instance.
+`solver-tolerance` -- `fast`, `w8`, `w8s`, ... (FMA contraction, reassociated sums, hoisted tape): not bit-identical; a
+Newton line-search decision can flip on a 1e-17 residue (see tests/test_oracle_sls.py), so the stated tolerance is
+the solver's own (desiredDualityGap=1e-5, gradTolerance=1e-4): same status on every instance, |iter difference| <= 2,
+|J-J_ref| <= 5e-5, |x-x_ref| <= 5e-5, box-KKT residual <= 1e-4; the fraction of instances whose KKT residual is within
+1e-10 of the oracle's (the north-star criterion) is computed over ALL instances, printed, and must stay above the
+floor stated per variant -- these lowerings do NOT meet that criterion on every instance, which is why they are not
+the benchmark default.
 """
 import os
 
@@ -49,10 +53,14 @@ def _oracle_batch(spec, tape_path, A, b, x0, **kw):
                           c + "_set_x": x0}, c + "_getOutputs", B, **args)
 
 
-def test_strict_bit_exact_vs_oracle(libs, sls_spec, sls_tape_path):
-    B = 1000                               # ragged: not a multiple of the 64-wide wavefront
+BIT_EXACT = ["sls_strict", "sls_w8x"]
+
+
+@pytest.mark.parametrize("variant", BIT_EXACT)
+def test_strict_bit_exact_vs_oracle(libs, sls_spec, sls_tape_path, variant):
+    B = 1003                               # ragged: not a multiple of the 64-wide wavefront, nor of 8
     A, b, x0 = sls_batch(B, seed0=1000)
-    obj = _load(libs["sls_strict"], B)
+    obj = _load(libs[variant], B)
     _set(obj, A, b, x0)
     st, it, t = obj.solve(**SOLVE_ARGS)
     J, x = obj.getOutputs()
@@ -62,11 +70,12 @@ def test_strict_bit_exact_vs_oracle(libs, sls_spec, sls_tape_path):
     assert (st == 0).all()
 
 
-def test_strict_golden_vectors(libs):
+@pytest.mark.parametrize("variant", BIT_EXACT)
+def test_strict_golden_vectors(libs, variant):
     g = np.load(GOLD)
     B = len(g["seeds"])
     A, b, x0 = sls_batch(B, seed0=int(g["seeds"][0]))
-    obj = _load(libs["sls_strict"], B)
+    obj = _load(libs[variant], B)
     _set(obj, A, b, x0)
     st, it, _ = obj.solve(**SOLVE_ARGS)
     J, x = obj.getOutputs()
@@ -87,16 +96,26 @@ def test_strict_tape_probes_golden(libs):
         assert np.array_equal(got, g["probe_" + p].reshape(B, -1)), p
 
 
-def test_strict_edge_cases_status_bits(libs, sls_spec, sls_tape_path):
-    """maxIter exhaustion (status 8|...), NaN parameters (status 4), B=1, other mu0/addEye."""
-    B = 130
+@pytest.mark.parametrize("variant", BIT_EXACT)
+def test_strict_edge_cases_status_bits(libs, sls_spec, sls_tape_path, variant):
+    """maxIter exhaustion (status 8|...), NaN parameters (status 4; for w8x: in one lane group of a wavefront, and
+    a NaN that the reference's min/max chains SKIP because it is not their first operand), an infeasible start
+    (status 1), zeros (the sign of a zero minimum is order dependent), negative curvature (second regularisation
+    pass), B=1, other mu0/addEye."""
+    B = 131
     A, b, x0 = sls_batch(B, seed0=5000)
     A[3] *= np.nan
     b[5] *= 1e6
     A[7] *= 0
     x0[9] = .05 - 1e-13
-    for kw in [dict(mu0=1.0, maxIter=4), dict(mu0=1e-3, maxIter=30), dict(mu0=10.0, maxIter=60, addEye2Hessian=(1e-3, 1e-3))]:
-        obj = _load(libs["sls_strict"], B)
+    x0[11] = .06                                  # outside the box
+    x0[13, 3] = 0.0                               # on the boundary: min F == 0 exactly
+    x0[15, 2] = np.nan                            # NaN in one component of the initial point only
+    b[17, 40] = np.nan                            # NaN in one row of b only
+    A[19] = 0; b[19] = 0                          # zero gradient: max_abs == 0
+    for kw in [dict(mu0=1.0, maxIter=4), dict(mu0=1e-3, maxIter=30), dict(mu0=10.0, maxIter=60, addEye2Hessian=(1e-3, 1e-3)),
+               dict(mu0=1.0, maxIter=30, addEye2Hessian=(-1.0, -1.0))]:
+        obj = _load(libs[variant], B)
         _set(obj, A, b, x0)
         st, it, _ = obj.solve(**{**SOLVE_ARGS, **kw})
         J, x = obj.getOutputs()
@@ -105,7 +124,7 @@ def test_strict_edge_cases_status_bits(libs, sls_spec, sls_tape_path):
         assert np.array_equal(J.reshape(B), ref[:, 0], equal_nan=True)
         assert np.array_equal(x.reshape(B, 8), ref[:, 1:], equal_nan=True)
         assert st[3] == 4
-    one = _load(libs["sls_strict"], 1)
+    one = _load(libs[variant], 1)
     _set(one, A[:1], b[:1], x0[:1])
     st, it, _ = one.solve(**SOLVE_ARGS)
     ref, rst, rit = _oracle_batch(sls_spec, sls_tape_path, A[:1], b[:1], x0[:1])
@@ -168,6 +187,11 @@ def test_reference_c_surface_single_instance(libs, sls_spec, sls_tape_path):
     assert J.value == ref[0, 0] and np.array_equal(x, ref[0, 1:])
 
 
+# measured on MI355X (round 2; printed by the test): fraction of instances with KKT residual within 1e-10 of the
+# reference's -- floors a few points below the measurement
+KKT_FLOOR = {"sls_fast": 0.78, "sls_w8": 0.75, "sls_w8h": 0.73, "sls_regs": 0.58, "sls_regsl": 0.58, "sls_w8s": 0.73}
+
+
 @pytest.mark.parametrize("variant", ["sls_fast", "sls_w8", "sls_w8h", "sls_regs", "sls_regsl", "sls_w8s"])
 def test_fast_build_within_stated_tolerance(libs, sls_spec, sls_tape_path, variant):
     """reassociating lowerings (fast, w8) and the hoisted tape (w8h, regs: tenscalc_amd/hoist.py) against
@@ -195,9 +219,15 @@ def test_fast_build_within_stated_tolerance(libs, sls_spec, sls_tape_path, varia
         return np.abs(xv - np.clip(xv - gr, 0, .05)).max(axis=1)
     r_gpu, r_ref = kkt(x), kkt(ref[:, 1:])
     assert r_gpu.max() <= 1e-4 and r_ref.max() <= 1e-4          # both are solutions to solver tolerance
-    noflip = (it == rit) & (np.abs(x - ref[:, 1:]).max(axis=1) <= 1e-9)
-    assert noflip.mean() > 0.5
-    assert np.abs(r_gpu - r_ref)[noflip].max() <= 1e-10          # north-star criterion where no branch flipped
+    # the north-star criterion, over ALL instances (no self-selected subset): fraction with KKT residual within
+    # 1e-10 of the reference's.  These lowerings do not reach 1.0 (a flipped line-search branch moves the
+    # returned point by ~1e-8..5e-6); the floor catches a regression, the printed number is the honest one
+    within = np.abs(r_gpu - r_ref) <= 1e-10
+    same_it = it == rit
+    print("\n%s: |dKKT|<=1e-10 on %.4f of %d instances; same iteration count on %.4f; max|dKKT| %.3g, max|dx| %.3g"
+          % (variant, within.mean(), B, same_it.mean(), np.abs(r_gpu - r_ref).max(), np.abs(x - ref[:, 1:]).max()))
+    assert within.mean() >= KKT_FLOOR[variant], (variant, within.mean())
+    assert np.abs(r_gpu - r_ref).max() <= 1e-5
 
 
 def test_device_resident_inputs_both_layouts(libs, sls_spec, sls_tape_path):
@@ -222,10 +252,49 @@ def test_device_resident_inputs_both_layouts(libs, sls_spec, sls_tape_path):
         assert np.array_equal(x.reshape(B, 8), ref[:, 1:])
 
 
-def test_full_batch_properties(libs):
+def test_bench_default_bit_exact_on_bench_batch(libs, sls_spec, sls_tape_path):
+    """bench.py's default variant on bench.py's own batch (B=65536, the generator of bench.make_batch): status,
+    iteration count and outputs of 4096 + 1024 instances of that batch are bit-identical to the oracle, and the
+    other bit-exact lowering (strict) agrees with it bit for bit on ALL 65536."""
+    import torch
+    import __graft_entry__ as g
+    import bench
+    from tenscalc_amd.runtime import LAYOUT_BATCH_MINOR
+    assert g.PARITY_CLASS[g.BENCH_DEFAULT] == "bit-exact"
+    B = 65536
+    A, b, x0 = bench.make_batch(B, 0, torch.device("cuda", 0))
+    res = {}
+    for tag in ("sls_" + g.BENCH_DEFAULT, "sls_strict"):
+        obj = _load(libs[tag], B)
+        for nm, t in (("A", A), ("b", b), ("x", x0)):
+            obj.set_device(nm, t, LAYOUT_BATCH_MINOR)
+        obj.synchronize()
+        st, it, _ = obj.solve(**SOLVE_ARGS)
+        J, x = obj.getOutputs()
+        res[tag] = (st, it, J.reshape(B), x.reshape(B, 8))
+        obj.close()
+    d, s_ = res["sls_" + g.BENCH_DEFAULT], res["sls_strict"]
+    assert all(np.array_equal(a_, b_) for a_, b_ in zip(d, s_))
+    assert (d[0] == 0).all()
+    sel = np.concatenate([np.arange(4096), np.random.RandomState(3).choice(np.arange(4096, B), 1024, replace=False)])
+    Ah = A[:, torch.from_numpy(sel).cuda()].t().cpu().numpy()           # [k][800]: column-major A of instance k
+    bh = b[:, torch.from_numpy(sel).cuda()].t().cpu().numpy()
+    xh = x0[:, torch.from_numpy(sel).cuda()].t().cpu().numpy()
+    from oracle.tc_oracle import Oracle
+    c = sls_spec.classname
+    ref, rst, rit = Oracle(sls_tape_path).solve_batch({c + "_set_A": Ah, c + "_set_b": bh, c + "_set_x": xh},
+                                                      c + "_getOutputs", len(sel), mu0=SOLVE_ARGS["mu0"],
+                                                      maxIter=SOLVE_ARGS["maxIter"])
+    assert np.array_equal(d[0][sel], rst) and np.array_equal(d[1][sel], rit)
+    assert np.array_equal(d[2][sel], ref[:, 0]) and np.array_equal(d[3][sel], ref[:, 1:])
+
+
+@pytest.mark.parametrize("variant", ["sls_strict", "sls_w8x", "sls_w8s"])
+def test_full_batch_properties(libs, variant):
     """BASELINE config 2 size (B=65536): properties that need no CPU oracle -- every instance
     converges, respects the box, satisfies the KKT tolerances, is invariant to where it sits in the
-    batch (permutation), and a second solve() reproduces the first bit-for-bit."""
+    batch (permutation), and a second solve() reproduces the first bit-for-bit.  Run for the benchmark default
+    (w8x), the other bit-exact lowering and the solver-tolerance variant bench.py offers as --variant w8s."""
     import torch
     B = 65536
     g = torch.Generator(device="cuda").manual_seed(1)
@@ -233,7 +302,7 @@ def test_full_batch_properties(libs):
     b = torch.rand((100, B), generator=g, device="cuda", dtype=torch.float64)
     x0 = .02 * torch.rand((8, B), generator=g, device="cuda", dtype=torch.float64)
     from tenscalc_amd.runtime import LAYOUT_BATCH_MINOR
-    obj = _load(libs["sls_strict"], B)
+    obj = _load(libs[variant], B)
     for nm, t in (("A", A), ("b", b), ("x", x0)):
         obj.set_device(nm, t, LAYOUT_BATCH_MINOR)
     obj.synchronize()
@@ -249,7 +318,7 @@ def test_full_batch_properties(libs):
     J2, x2 = obj.getOutputs()
     assert np.array_equal(st, st2) and np.array_equal(it, it2) and np.array_equal(x2.reshape(B, 8), x)
     perm = torch.randperm(B, generator=torch.Generator().manual_seed(2)).cuda()
-    obj2 = _load(libs["sls_strict"], B)
+    obj2 = _load(libs[variant], B)
     for nm, t in (("A", A), ("b", b), ("x", x0)):
         obj2.set_device(nm, t[:, perm].contiguous(), LAYOUT_BATCH_MINOR)
     obj2.synchronize()
@@ -307,7 +376,7 @@ def test_odd_sized_sls_both_lowerings(libs, tmp_path):
     c = spec.classname
     ref, rst, rit = Oracle(tape).solve_batch({c + "_set_A": At.reshape(B, -1), c + "_set_b": b, c + "_set_x": x0},
                                              c + "_getOutputs", B, mu0=1.0, maxIter=30)
-    for tag, exact in (("sls37_strict", True), ("sls37_w8", False), ("sls37_w8s", False)):
+    for tag, exact in (("sls37_strict", True), ("sls37_w8x", True), ("sls37_w8", False), ("sls37_w8s", False)):
         obj = _load(libs[tag], B)
         obj.setP_A(At); obj.setP_b(b); obj.setV_x(x0)
         st, it, _ = obj.solve(**SOLVE_ARGS)
@@ -352,6 +421,11 @@ def test_receding_horizon_warm_start_on_device(libs):
     assert not np.array_equal(res[0], res[1])          # the warm start did change the problem data
 
 
+# largest |dx| the solver-tolerance lowering w8 may show on the template-branch problems (measured round 2, printed by
+# the test; "eq" runs with scaleCost, whose duality-gap test is ~40x looser)
+W8_DX_TOL = {"eq": 1e-3, "eqonly": 1e-9, "free": 1e-9}
+
+
 @pytest.mark.parametrize("kind", ["eq", "eqonly", "free"])
 def test_template_branches_on_gpu(libs, tmp_path, kind):
     """device Newton loop under the other #if combinations (nG>0 + useInertia + uncoupled alphas +
@@ -372,7 +446,7 @@ def test_template_branches_on_gpu(libs, tmp_path, kind):
                                              c + "_getOutputs", B, mu0=1e-2, maxIter=40)
     # strict_share: the bit-exact lowering with LDS/scratch slots shared by life time (soundness of the sharing)
     for tag, exact in (("small_%s_strict" % kind, True), ("small_%s_strict_share" % kind, True),
-                       ("small_%s_w8" % kind, False)):
+                       ("small_%s_w8x" % kind, True), ("small_%s_w8" % kind, False)):
         obj = _load(libs[tag], B)
         obj.setP_A(At); obj.setP_b(b); obj.setV_x(x0)
         st, it, _ = obj.solve(mu0=1e-2, maxIter=40)
@@ -381,13 +455,16 @@ def test_template_branches_on_gpu(libs, tmp_path, kind):
         if exact:
             assert np.array_equal(st, rst) and np.array_equal(it, rit) and np.array_equal(got, ref, equal_nan=True)
         else:
-            # solver-tolerance comparison (scaleCost loosens the duality-gap test by |10/J| ~ 40x, and a
-            # flipped line-search branch then moves weakly determined components by up to ~1e-3):
-            # the objective must agree tightly, the bulk of the instances to rounding
-            ok = (st == 0) & (rst == 0)
-            assert ok.mean() > 0.9 and (st[ok] == rst[ok]).all()
-            d = np.abs(got[ok] - ref[ok])
-            assert d[:, 0].max() <= 1e-4 and np.quantile(d.max(axis=1), 0.8) <= 1e-6 and d.max() <= 1e-2
+            # solver-tolerance class: the same status on EVERY instance, the objective within the solver's
+            # tolerance on every instance (scaleCost loosens the duality-gap test of kind "eq" by |10/J| ~ 40x, so a
+            # flipped line-search branch can move weakly determined components of x further than J)
+            d = np.abs(got - ref)
+            same = np.array_equal(st, rst)
+            print("\n%s: same status on %.4f of %d instances, max|dJ| %.3g, max|dx| %.3g, 80%% quantile %.3g"
+                  % (tag, (st == rst).mean(), B, np.nanmax(d[:, 0]), np.nanmax(d[:, 1:]), np.nanquantile(d.max(axis=1), 0.8)))
+            assert same
+            assert np.nanmax(d[:, 0]) <= 1e-4 and np.nanquantile(d.max(axis=1), 0.8) <= 1e-6
+            assert np.nanmax(d[:, 1:]) <= W8_DX_TOL[kind]
 
 
 def test_slot_sharing_is_bit_exact(libs, sls_spec, sls_tape_path):
@@ -401,12 +478,13 @@ def test_slot_sharing_is_bit_exact(libs, sls_spec, sls_tape_path):
     # addEye2Hessian < 0: negative curvature, the second pass of the regularisation loop runs (the only case in
     # which groups are re-evaluated inside one Newton iteration after a set)
     for maxIter, ae in ((30, (1e-9, 1e-9)), (4, (1e-9, 1e-9)), (30, (-10.0, -10.0)), (30, (-1.0, -1.0))):
-        obj = _load(libs["sls_strict_share"], B)
-        _set(obj, A, b, x0)
-        args = dict(SOLVE_ARGS, maxIter=maxIter, addEye2Hessian=ae)
-        st, it, _ = obj.solve(**args)
-        J, x = obj.getOutputs()
         ref, rst, rit = _oracle_batch(sls_spec, sls_tape_path, A, b, x0, maxIter=maxIter, addEye2Hessian=ae)
-        assert np.array_equal(st, rst) and np.array_equal(it, rit)
-        assert np.array_equal(J.reshape(B), ref[:, 0], equal_nan=True)
-        assert np.array_equal(x.reshape(B, 8), ref[:, 1:], equal_nan=True)
+        for tag in ("sls_strict_share", "sls_w8x"):        # w8x shares slots too (pushed groups keep their own)
+            obj = _load(libs[tag], B)
+            _set(obj, A, b, x0)
+            args = dict(SOLVE_ARGS, maxIter=maxIter, addEye2Hessian=ae)
+            st, it, _ = obj.solve(**args)
+            J, x = obj.getOutputs()
+            assert np.array_equal(st, rst) and np.array_equal(it, rit), tag
+            assert np.array_equal(J.reshape(B), ref[:, 0], equal_nan=True), tag
+            assert np.array_equal(x.reshape(B, 8), ref[:, 1:], equal_nan=True), tag
