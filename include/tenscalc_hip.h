@@ -19,6 +19,15 @@
  * All functions return 0 on success or a negative TC_E* code; numerical failures are reported
  * per instance through the reference's `status` bits (lib/private/parameters4all.m:311-332).
  * Plain C types only; `stream` arguments are hipStream_t passed as void*.
+ *
+ * Devices and streams.  Every entry point makes the handle's device current on the calling thread.  Each
+ * handle owns one stream; entry points without a `stream` argument (tc_set, tc_solve, tc_get_outputs,
+ * tc_probe, tc_synchronize, ...) run on it.  tc_set_device / tc_set_from_output / tc_solve_async accept a
+ * caller's stream (NULL = the handle's): work enqueued there is ordered AFTER everything the handle's stream
+ * already holds and BEFORE anything enqueued later on the handle's stream (an event links the two), so
+ * tc_solve_async(h,...,s) followed by tc_get_outputs(h,...) reads finished results, and a tc_set cannot
+ * overwrite inputs a solve on another stream is still reading.  Two DIFFERENT caller streams are not ordered
+ * with respect to each other by the library.
  */
 #ifndef TENSCALC_HIP_H
 #define TENSCALC_HIP_H

@@ -32,8 +32,15 @@ typedef struct {
   int (*nout)(void);
   int (*ondim)(int);
   int64_t (*odim)(int, int);
+  int (*nin)(void);
+  const char *(*iname)(int);
+  int64_t (*inumel)(int);
   const char *(*err)(void);
 } obj_t;
+
+static void need(int ok, const char *msg) {
+  if (!ok) mexErrMsgIdAndTxt("tenscalc:hip", "tc_mex: %s", msg);
+}
 
 static void check(obj_t *o, int rc, const char *what) {
   if (rc) mexErrMsgIdAndTxt("tenscalc:hip", "%s failed (%d): %s", what, rc, o->err());
@@ -44,7 +51,10 @@ void mexFunction(int nlhs, mxArray *plhs[], int nrhs, const mxArray *prhs[]) {
   if (nrhs < 1 || mxGetString(prhs[0], cmd, sizeof cmd)) mexErrMsgTxt("tc_mex: command string expected");
   if (!strcmp(cmd, "create")) {
     char path[4096];
-    mxGetString(prhs[1], path, sizeof path);
+    need(nrhs == 3 && mxIsChar(prhs[1]) && mxIsNumeric(prhs[2]) && mxGetNumberOfElements(prhs[2]) == 1,
+         "create: (libpath, B) expected");
+    need(!mxGetString(prhs[1], path, sizeof path), "create: library path too long");
+    need(mxGetScalar(prhs[2]) >= 1, "create: B must be >= 1");
     obj_t *o = (obj_t *)mxCalloc(1, sizeof *o);
     mexMakeMemoryPersistent(o);
     o->lib = dlopen(path, RTLD_NOW | RTLD_LOCAL);
@@ -57,20 +67,41 @@ void mexFunction(int nlhs, mxArray *plhs[], int nrhs, const mxArray *prhs[]) {
     *(void **)&o->nout = dlsym(o->lib, "tc_num_outputs");
     *(void **)&o->ondim = dlsym(o->lib, "tc_output_ndim");
     *(void **)&o->odim = dlsym(o->lib, "tc_output_dim");
+    *(void **)&o->nin = dlsym(o->lib, "tc_num_inputs");
+    *(void **)&o->iname = dlsym(o->lib, "tc_input_name");
+    *(void **)&o->inumel = dlsym(o->lib, "tc_input_numel");
     *(void **)&o->err = dlsym(o->lib, "tc_last_error");
+    if (!o->create || !o->destroy || !o->set || !o->solve || !o->get || !o->nout || !o->ondim || !o->odim ||
+        !o->nin || !o->iname || !o->inumel || !o->err)
+      mexErrMsgIdAndTxt("tenscalc:hip", "%s is not a TensCalc-HIP class library (missing tc_* symbols)", path);
     o->B = (int64_t)mxGetScalar(prhs[2]);
     check(o, o->create(o->B, 0, &o->h), "tc_create");
     plhs[0] = mxCreateNumericMatrix(1, 1, mxUINT64_CLASS, mxREAL);
     *(uint64_t *)mxGetData(plhs[0]) = (uint64_t)(uintptr_t)o;
     return;
   }
+  need(nrhs >= 2 && mxIsUint64(prhs[1]) && mxGetNumberOfElements(prhs[1]) == 1, "handle (uint64 scalar) expected");
   obj_t *o = (obj_t *)(uintptr_t)(*(uint64_t *)mxGetData(prhs[1]));
+  need(o != NULL && o->h != NULL, "handle already destroyed");
   if (!strcmp(cmd, "set")) {
     char name[256];
-    mxGetString(prhs[2], name, sizeof name);
+    need(nrhs == 4 && mxIsChar(prhs[2]), "set: (h, name, value) expected");
+    need(!mxGetString(prhs[2], name, sizeof name), "set: name too long");
+    need(mxIsDouble(prhs[3]) && !mxIsComplex(prhs[3]) && !mxIsSparse(prhs[3]), "set: value must be a full real double array");
+    int64_t numel = -1;
+    for (int k = 0; k < o->nin(); k++)
+      if (!strcmp(o->iname(k), name)) numel = o->inumel(k);
+    need(numel >= 0, "set: the class has no such parameter/variable");
+    /* exactly numel*B doubles: tc_set reads that many from the pointer */
+    need((int64_t)mxGetNumberOfElements(prhs[3]) == numel * o->B, "set: value must have prod(size)*B elements ([size...,B])");
     /* MATLAB [size...,B] column-major == the C-ABI's instance-major host layout */
     check(o, o->set(o->h, name, mxGetPr(prhs[3]), o->B), "tc_set");
   } else if (!strcmp(cmd, "solve")) {
+    need(nrhs == 5 || nrhs == 6, "solve: (h, mu0, int32(maxIter), int32(saveIter)[, addEye2Hessian]) expected");
+    need(mxIsDouble(prhs[2]) && mxGetNumberOfElements(prhs[2]) == 1, "solve: mu0 must be a double scalar");
+    need(mxIsInt32(prhs[3]) && mxGetNumberOfElements(prhs[3]) == 1, "solve: maxIter must be an int32 scalar");
+    need(mxIsInt32(prhs[4]) && mxGetNumberOfElements(prhs[4]) == 1, "solve: saveIter must be an int32 scalar");
+    need(nrhs < 6 || (mxIsDouble(prhs[5]) && mxGetNumberOfElements(prhs[5]) == 2), "solve: addEye2Hessian must be 2 doubles");
     double mu0 = mxGetScalar(prhs[2]), tm = 0;
     int32_t maxIter = *(int32_t *)mxGetData(prhs[3]), saveIter = *(int32_t *)mxGetData(prhs[4]);
     double ae_default[2] = {1e-9, 1e-9};   /* template default, cmex2optimizeCS.m:291 */
@@ -83,8 +114,9 @@ void mexFunction(int nlhs, mxArray *plhs[], int nrhs, const mxArray *prhs[]) {
     if (nlhs > 2) plhs[2] = mxCreateDoubleScalar(tm);
   } else if (!strcmp(cmd, "get")) {
     int n = o->nout();
-    double *ptr[64];
-    for (int k = 0; k < n && k < 64; k++) {
+    need(nlhs <= n, "get: more outputs requested than the class has");
+    double **ptr = (double **)mxCalloc(n > 0 ? n : 1, sizeof *ptr);   /* tc_get_outputs reads exactly n pointers */
+    for (int k = 0; k < n; k++) {
       mwSize dims[9];
       int nd = o->ondim(k);
       for (int d = 0; d < nd; d++) dims[d] = (mwSize)o->odim(k, d);
@@ -93,9 +125,12 @@ void mexFunction(int nlhs, mxArray *plhs[], int nrhs, const mxArray *prhs[]) {
       ptr[k] = mxGetPr(a);
       if (k < nlhs || k == 0) plhs[k] = a;
     }
-    check(o, o->get(o->h, ptr, o->B), "tc_get_outputs");
+    int rc = o->get(o->h, ptr, o->B);
+    mxFree(ptr);
+    check(o, rc, "tc_get_outputs");
   } else if (!strcmp(cmd, "destroy")) {
     o->destroy(o->h);
+    o->h = NULL;
     dlclose(o->lib);
     mxFree(o);
   } else {

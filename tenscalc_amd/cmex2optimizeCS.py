@@ -104,7 +104,18 @@ def cmex2optimizeCS(*, classname, objective, optimizationVariables, constraints=
     parameter-only factors in the derivatives are contracted first, so they are evaluated once
     per solve instead of once per Newton iteration.  Same mathematics, different rounding.
 
-    Unsupported reference options raise, exactly as ipmPD_CStimesLambda.m:31-48 does."""
+    Unsupported reference options raise, exactly as ipmPD_CStimesLambda.m:31-48 does; unknown (misspelled)
+    options raise too, as FunParTools' setParameters does for the reference."""
+    if ignored:
+        accepted_noop = {"compilerOptimization", "compileGateways", "compileLibrary", "compileStandalones",
+                         "callType", "sensitivityVariables", "simulinkLibrary", "dummyLibrary", "pedigreeClass",
+                         "executeScript", "useSparsityPatterns", "minInstructions4loop", "maxInstructionsPerFunction",
+                         "absolutePath", "serverProgramName", "serverAddress", "port", "profiling", "umfpack",
+                         "debugConvergence", "debugConvergenceThreshold", "scratchbookType", "fastRedundancyCheck",
+                         "codeType", "targetComputer", "serverComputer", "parametersStructure", "parametersMfile"}
+        bad = sorted(set(ignored) - accepted_noop)
+        if bad:
+            raise TypeError("cmex2optimizeCS: unknown option(s) %s" % ", ".join(bad))
     if not skipAffine:
         raise NotImplementedError("skipAffine=false not implemented (ipmPD_CStimesLambda.m:37-39)")
     if smallerNewtonMatrix:

@@ -41,7 +41,25 @@ int main(int argc, char **argv) {
   tc_solver_t *h;
   if (create(B, 0, &h)) { fprintf(stderr, "tc_create: %s\n", lasterr()); return 6; }
   if (set(h, "A", A, B) || set(h, "b", b, B) || set(h, "x", x0, B)) { fprintf(stderr, "tc_set: %s\n", lasterr()); return 6; }
+  /* error codes of the boundary (API-level failures as non-zero return codes, never a crash) */
   if (set(h, "nosuchinput", A, B) != TC_EINVAL) { fprintf(stderr, "bad name accepted\n"); return 7; }
+  if (set(h, "A", A, B + 1) != TC_EINVAL) { fprintf(stderr, "batch mismatch accepted by tc_set\n"); return 7; }
+  if (set(h, "A", NULL, B) != TC_EINVAL || set(NULL, "A", A, B) != TC_EINVAL) { fprintf(stderr, "null accepted\n"); return 7; }
+  if (!lasterr()[0]) { fprintf(stderr, "tc_last_error empty after a failure\n"); return 7; }
+  {
+    tc_solver_t *bad = (tc_solver_t *)1;
+    if (create(0, 0, &bad) != TC_EINVAL || create(-5, 0, &bad) != TC_EINVAL) { fprintf(stderr, "B<=0 accepted\n"); return 7; }
+    if (create(4, 1000, &bad) != TC_EINVAL || bad != NULL) { fprintf(stderr, "device 1000 accepted\n"); return 7; }
+    if (create(4, 0, NULL) != TC_EINVAL) { fprintf(stderr, "null out accepted\n"); return 7; }
+    if (destroy(NULL) != TC_EINVAL) { fprintf(stderr, "destroy(NULL) accepted\n"); return 7; }
+    double *o2[2] = {0, 0};
+    int (*get_)(tc_solver_t *, double **, int64_t);
+    *(void **)&get_ = dlsym(lib, "tc_get_outputs");
+    if (get_(h, o2, B + 3) != TC_EINVAL || get_(h, NULL, B) != TC_EINVAL) { fprintf(stderr, "tc_get_outputs: bad arguments accepted\n"); return 7; }
+    /* several handles at once, destroyed in any order (handle-based, no global state besides the B=1 compat one) */
+    tc_solver_t *h2, *h3;
+    if (create(3, 0, &h2) || create(5, 0, &h3) || destroy(h2) || destroy(h3)) { fprintf(stderr, "second/third handle: %s\n", lasterr()); return 7; }
+  }
   double mu0 = 1.0, ae[2] = {1e-9, 1e-9}, tm = 0;
   int32_t maxIter = 30, saveIter = -1;
   int32_t *status = malloc(sizeof(int32_t) * B), *iter = malloc(sizeof(int32_t) * B);
@@ -49,6 +67,16 @@ int main(int argc, char **argv) {
   double *J = malloc(sizeof(double) * B), *x = malloc(sizeof(double) * B * 8);
   double *outs[2] = {J, x};
   if (get(h, outs, B)) { fprintf(stderr, "tc_get_outputs: %s\n", lasterr()); return 6; }
+  {
+    /* enqueue-only solve followed by tc_get_outputs without an explicit synchronisation (header: stream rule) */
+    int (*solve_async)(tc_solver_t *, double, int32_t, const double *, void *);
+    SYM(solve_async, "tc_solve_async")
+    double *J2 = malloc(sizeof(double) * B), *x2 = malloc(sizeof(double) * B * 8);
+    double *outs2[2] = {J2, x2};
+    if (set(h, "x", x0, B) || solve_async(h, mu0, maxIter, ae, NULL) || get(h, outs2, B)) { fprintf(stderr, "async path: %s\n", lasterr()); return 6; }
+    if (memcmp(J, J2, sizeof(double) * B) || memcmp(x, x2, sizeof(double) * B * 8)) { fprintf(stderr, "async solve + get differs from tc_solve\n"); return 9; }
+    free(J2); free(x2);
+  }
   destroy(h);
 
   /* the reference's own symbols, one instance (writeCfunctionpergroup.m:524,607-635; ipmPD_CSsolver.c:132-141) */

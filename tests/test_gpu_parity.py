@@ -252,6 +252,36 @@ def test_device_resident_inputs_both_layouts(libs, sls_spec, sls_tape_path):
         assert np.array_equal(x.reshape(B, 8), ref[:, 1:])
 
 
+def test_caller_stream_is_ordered_with_the_handle_stream(libs, sls_spec, sls_tape_path):
+    """include/tenscalc_hip.h "Devices and streams": inputs stored and a solve enqueued on a CALLER's stream,
+    then getOutputs / set on the handle's own stream without any explicit synchronisation -- the results are those
+    of the synchronous path (an event links the two streams; before, the transpose of getOutputs could read
+    outputs the solve had not written yet)."""
+    import torch
+    from tenscalc_amd.runtime import LAYOUT_BATCH_MINOR
+    B = 16384
+    g_ = torch.Generator(device="cuda").manual_seed(7)
+    A = torch.rand((800, B), generator=g_, device="cuda", dtype=torch.float64)
+    b = torch.rand((100, B), generator=g_, device="cuda", dtype=torch.float64)
+    x0 = .02 * torch.rand((8, B), generator=g_, device="cuda", dtype=torch.float64)
+    ref = _load(libs["sls_w8x"], B)
+    for nm, t in (("A", A), ("b", b), ("x", x0)):
+        ref.set_device(nm, t, LAYOUT_BATCH_MINOR)
+    st0, it0, _ = ref.solve(**SOLVE_ARGS)
+    J0, x0_ = ref.getOutputs()
+    side = torch.cuda.Stream()
+    obj = _load(libs["sls_w8x"], B)
+    for rep in range(3):
+        with torch.cuda.stream(side):
+            for nm, t in (("A", A), ("b", b), ("x", x0)):
+                obj.set_device(nm, t, LAYOUT_BATCH_MINOR, stream=side.cuda_stream)
+            obj.solve_async(SOLVE_ARGS["mu0"], SOLVE_ARGS["maxIter"], SOLVE_ARGS["addEye2Hessian"], stream=side.cuda_stream)
+        J, x = obj.getOutputs()                                   # handle stream: must wait for the side stream
+        assert np.array_equal(J, J0) and np.array_equal(x, x0_), rep
+        obj.set("x", np.zeros((B, 8)))                            # handle stream again; the next round overwrites it
+    obj.close(); ref.close()
+
+
 def test_bench_default_bit_exact_on_bench_batch(libs, sls_spec, sls_tape_path):
     """bench.py's default variant on bench.py's own batch (B=65536, the generator of bench.make_batch): status,
     iteration count and outputs of 4096 + 1024 instances of that batch are bit-identical to the oracle, and the
@@ -389,26 +419,45 @@ def test_odd_sized_sls_both_lowerings(libs, tmp_path):
             assert np.abs(it - rit).max() <= 2 and np.abs(got - ref).max() <= 5e-5
 
 
-def test_receding_horizon_warm_start_on_device(libs):
+def test_receding_horizon_warm_start_on_device(libs, tmp_path):
     """MPC loop of examples/mpcmhe/mpc_dcmotor.m:192-225 (setV_u(uWarm); setV_x(xWarm) from the previous
-    outputs): feeding the warm-start outputs back on the device equals the host round trip bit-for-bit."""
+    outputs), three receding-horizon steps: the HIP path with the warm start fed back ON THE DEVICE
+    (tc_set_from_output) is bit-identical, step by step, to the ORACLE running the same loop on the host (its
+    getOutputs fed back through its sets), and to the HIP path with a host round trip."""
     import __graft_entry__ as g
     from tenscalc_amd.problems.mpc_dcmotor import SOLVE_ARGS as DC_ARGS, dcmotor_data, mpc_dcmotor
+    from tenscalc_amd.tapeio import save_tape
+    from oracle.tc_oracle import Oracle
     spec = mpc_dcmotor(folder=g.GENERATED)
+    tape = str(tmp_path / "dc.tape")
+    save_tape(spec.tape, tape)
+    orc = Oracle(tape)
+    c = spec.classname
     B = 64
     data = [dcmotor_data(2000 + k) for k in range(B)]
     names = [n for n, _ in spec.parameters + spec.variables]
+    stacked = {n: np.stack([np.asarray(d[n], dtype=float).reshape(-1, order="F") for d in data]) for n in names}
     objs = [_load(libs["dcmotor_strict"], B) for _ in range(2)]
     for obj in objs:
         for n in names:
-            obj.set(n, np.stack([np.asarray(d[n], dtype=float).reshape(-1, order="F") for d in data]))
+            obj.set(n, stacked[n])
+    onames = [nm for nm, _ in spec.outputs]
+    osize = [int(np.prod(sz)) if len(sz) else 1 for _, sz in spec.outputs]
+    ooff = np.concatenate([[0], np.cumsum(osize)])
+    cur = dict(stacked)                       # the oracle's inputs, step by step
     res = []
     for step in range(3):
+        ref, rst, rit = orc.solve_batch({f"{c}_set_{n}": cur[n] for n in names}, c + "_getOutputs", B,
+                                        mu0=DC_ARGS["mu0"], maxIter=DC_ARGS["maxIter"])
+        rout = {nm: ref[:, ooff[k]:ooff[k + 1]] for k, nm in enumerate(onames)}
         st = []
         for which, obj in enumerate(objs):
             s_, it, _ = obj.solve(**DC_ARGS)
             out = obj.getOutputs(as_dict=True)
             st.append((s_, it, out["J"], out["x"]))
+            assert np.array_equal(s_, rst) and np.array_equal(it, rit), (step, which)
+            for nm in onames:
+                assert np.array_equal(out[nm].reshape(B, -1), rout[nm]), (step, which, nm)
             if which == 0:      # device-side feedback
                 obj.set_from_output("x", "xWarm")
                 obj.set_from_output("u", "uWarm")
@@ -418,6 +467,7 @@ def test_receding_horizon_warm_start_on_device(libs):
         assert all(np.array_equal(a, b) for a, b in zip(st[0], st[1])), step
         assert (st[0][0] == 0).all()
         res.append(st[0][2].copy())
+        cur = dict(cur, x=rout["xWarm"].copy(), u=rout["uWarm"].copy())
     assert not np.array_equal(res[0], res[1])          # the warm start did change the problem data
 
 
