@@ -1408,6 +1408,153 @@ def emit_class(spec, fp_contract="fast", block=64, stats=False, roll=True, min_w
     return "".join(w), L
 
 
+def emit_class_ldsm(spec, waves=4, stats=False, lds_slots=20000):
+    """body="ldsm": ONE instance per workgroup of `waves` wavefronts, hot state in LDS, the tape as data whose
+    records give every lane a different scalar instruction (csrc/tc_ldsm.hip.inc, ldsm_schedule.py)."""
+    from . import ldsm_schedule as lsch
+    T = spec.tape
+    cls = spec.classname
+    W = int(waves)
+    cs = lsch.class_stream(T, cls, spec.defines, W=W, lds_slots=lds_slots)
+    L = cs["lowering"]
+    addr = cs["addr"]
+    nW = max(1, (T.nGroups + 63) // 64)
+    w = []
+    w.append(f"// GENERATED by tenscalc_amd.hip_emitter (ldsm back-end) for class '{cls}' -- do not edit.\n"
+             f"// tape: {T.n} instructions, {T.nGroups} dependency groups; state: {cs['nLds']} LDS slots "
+             f"({cs['nHot']} hot shared, {cs['nLocal']} group-local scratch), {cs['nGlob']} doubles in HBM per instance "
+             f"({cs['nExt']} inputs, {cs['nCold']} cold); {len(cs['headers']) // 8} records, {len(cs['words'])} body words\n")
+    w.append("#include <hip/hip_runtime.h>\n#include <math.h>\n#include <float.h>\n#include <stdint.h>\n\n")
+    w.append(f'#define TC_CLASSNAME "{cls}"\n#define TC_BLOCK {64 * W}\n#define TC_P 1\n#define TC_G TC_BLOCK\n'
+             f"#define TC_NDIST 0\n#define TC_LDSM 1\n#define TC_W {W}\n#define TC_NLDS {cs['nLds']}\n#define TC_NGLOB {max(1, cs['nGlob'])}\n"
+             f"#define TC_LAUNCH_BOUNDS __launch_bounds__(TC_BLOCK)\n")
+    if stats:
+        w.append("#define TC_STATS %d\n" % (2 if stats == "phases" else 1))
+    w.append("// solver configuration (reference: cmex2optimizeCS.m:303-331)\n")
+    for k in ["nU", "nG", "nF", "scaleCost", "scaleInequalities", "scaleEqualities", "coupledAlphas",
+              "setAddEye2Hessian", "adjustAddEye2Hessian", "useInertia", "delta", "skipAffine",
+              "smallerNewtonMatrix", "useLDL", "useUmfpack", "allowSave"]:
+        w.append(f"#define {k} {int(spec.defines[k])}\n")
+    for k in ["gradTolerance", "addEye2HessianUtolerance", "equalTolerance", "desiredDualityGap",
+              "alphaMin", "alphaMax", "muFactorAggressive", "muFactorConservative"]:
+        w.append(f"#define {k} {_lit(spec.defines[k])}\n")
+    nOut = cs["nOut"]
+    w.append(f"#define TC_NM {cs['nLds']}\n#define TC_NMP {cs['nLds']}\n#define TC_NEXT {cs['nExt']}\n#define TC_NOUT {nOut}\n"
+             f"#define TC_NGROUPS {T.nGroups}\n#define TC_NSTW {nW}\n\n")
+    w.append("typedef __attribute__((address_space(3))) double *tc_lds;\n"
+             "typedef const __attribute__((address_space(1))) double *tc_glob;\n"
+             "typedef __attribute__((address_space(1))) double *tc_gmem;\n"
+             "// per-instance context: m = the instance's LDS state, gm = its HBM array (inputs first); every lane of the\n"
+             "// block holds the same scalars and takes the same branches\n"
+             "struct TcCtx {\n  tc_lds m;\n  tc_gmem gm;\n  long B;\n  int lane;\n  unsigned long long st[TC_NSTW];\n"
+             "#ifdef TC_STATS\n  int nMinF;\n  long long cyc[TC_NGROUPS];\n  int cnt[TC_NGROUPS];\n  long long ph[8], tph;\n#endif\n};\n"
+             "#define TC_DIV(x, d) ((x) / (d))\n"
+             "static __device__ __forceinline__ double tc_min(double a, double x) { return (a > x) ? x : a; }\n"
+             "static __device__ __forceinline__ double tc_max(double a, double x) { return (a < x) ? x : a; }\n"
+             "static __device__ __forceinline__ double tc_clp(double a, double x, double dx) {\n"
+             "  if (dx < 0) { const double t = -x / dx; if (a > t) a = t; }\n  return a;\n}\n\n")
+    arr = lsch.as_array(cs["words"] + [0] * 64)
+    w.append(f"// the tape as data: {arr.size} body words, {len(cs['headers']) // 8} record headers\n"
+             "static __device__ const int tc_code[] __attribute__((aligned(64))) = {\n")
+    for k0 in range(0, arr.size, 32):
+        w.append(",".join(str(int(x)) for x in arr[k0:k0 + 32]) + ",\n")
+    harr = lsch.as_array(cs["headers"] + [0] * 16)
+    w.append("};\nstatic __device__ const int tc_hdr[] __attribute__((aligned(64))) = {\n")
+    for k0 in range(0, harr.size, 32):
+        w.append(",".join(str(int(x)) for x in harr[k0:k0 + 32]) + ",\n")
+    w.append("};\nstatic __device__ const int tc_rng[] __attribute__((aligned(64))) = {"
+             + ", ".join(str(int(x)) for x in cs["table"]) + ", 0, 0};\n"
+             "static __device__ const double tc_consts[] = {" + ", ".join(_lit(v) for _, v in cs["consts"]) + "};\n"
+             "static __device__ const int tc_const_addr[] = {" + ", ".join(str(int(a)) for a, _ in cs["consts"]) + "};\n"
+             f"#define TC_NCONST {len(cs['consts'])}\n"
+             '#include "tc_ldsm.hip.inc"\n\n')
+    for g, members in enumerate(T.groups, 1):
+        w.append(f"// group {g}: {len(members)} instructions in {cs['gstats'][g][1]} levels, {int(T.flops[g].sum())} flops\n"
+                 f"#define TC_CALL_GRP{g} tc_ldsm_run(c.m, c.gm, {cs['rid'][g]})\n")
+    w.append("\n#define TC_EVAL(g) do { c.st[((g)-1)>>6] |= 1ull << (((g)-1)&63); TC_CALL_GRP##g; } while (0)\n"
+             "#define TC_NEED(g) do { if (!((c.st[((g)-1)>>6] >> (((g)-1)&63)) & 1ull)) { "
+             "c.st[((g)-1)>>6] |= 1ull << (((g)-1)&63); TC_CALL_GRP##g; } } while (0)\n")
+
+    def inval(children):
+        s_ = ""
+        for wd in range(nW):
+            m = sum(1 << ((g - 1) % 64) for g in children if (g - 1) // 64 == wd)
+            if m:
+                s_ += f"  c.st[{wd}] &= ~0x{m:x}ull;\n"
+        return s_
+
+    def ref(i):
+        i = int(i)
+        if T.isload[i - 1]:
+            return _lit(float(T.pars[T.parStart[i - 1]]))
+        return f"TCL_LD({int(addr[i])})"
+    w.append("\n// ---- tape entry points (semantics: writeCfunctionpergroup.m:513-852)\n")
+    for e in T.sets:
+        if e["external"]:
+            continue
+        w.append(f"static __device__ __forceinline__ void {e['name']}(TcCtx &c, const double *input) {{\n"
+                 "  tc_block_sync();\n")        # the other waves of the block may still be reading
+        for k, i in enumerate(e["ins"]):
+            if addr[i] >= 0:
+                w.append(f"  TCL_ST({int(addr[i])}, input[{k}]);\n")
+        w.append(inval(e["children"]) + "}\n")
+    for e in T.gets:
+        args = ", ".join(f"double *y{k + 1}" for k in range(len(e["outputs"])))
+        w.append(f"static __device__ __forceinline__ void {e['name']}(TcCtx &c, {args}) {{\n")
+        for g in e["parents"]:
+            w.append(f"  TC_NEED({g});\n")
+        if e["name"].endswith("_getOutputs"):
+            w.append("  tc_block_sync();\n}\n")      # the kernel gathers the outputs itself
+            continue
+        w.append("  tc_block_sync();\n")
+        for k, o in enumerate(e["outputs"]):
+            for j, i in enumerate(o["ins"]):
+                w.append(f"  y{k + 1}[{j}] = {ref(i)};\n")
+        w.append("}\n")
+    for e in T.copies:
+        w.append(f"static __device__ __forceinline__ void {e['name']}(TcCtx &c) {{\n")
+        for g in e["parents"]:
+            w.append(f"  TC_NEED({g});\n")
+        w.append(f"  tc_ldsm_run(c.m, c.gm, {cs['rid'][e['name']]});\n" + inval(e["children"]) + "}\n")
+    w.append("\n#define TC_POW_HALF(x) sqrt(x)\n#include \"ipm_newton.hip.inc\"\n\n")
+    outs = T.entry(f"{cls}_getOutputs")[2]["outputs"]
+    gargs = ", ".join("(double *)0" for _ in outs)
+    w.append("extern \"C\" __global__ void TC_LAUNCH_BOUNDS\n"
+             "tc_solve_kernel(const double *__restrict__ S, const double *__restrict__ Sd, double *__restrict__ O,\n"
+             "                int *__restrict__ status, int *__restrict__ iter, double mu0, int maxIter, double ae0,\n"
+             "                double ae1, long B, double *__restrict__ dbg, double *__restrict__ Mg) {\n"
+             "  extern __shared__ double tc_lds_dyn[];\n"
+             "  const long tid = (long)blockIdx.x;\n  if (tid >= B) return;\n"
+             "  TcCtx c;\n  c.m = (tc_lds)tc_lds_dyn;\n  c.gm = (tc_gmem)(Mg + tid * (long)TC_NGLOB);\n  c.B = B;\n"
+             "  c.lane = (int)(threadIdx.x & 63);\n  for (int k = 0; k < TC_NSTW; k++) c.st[k] = 0;\n"
+             "#ifdef TC_STATS\n  c.nMinF = 0;\n  for (int k = 0; k < TC_NGROUPS; k++) { c.cyc[k] = 0; c.cnt[k] = 0; }\n"
+             "  for (int k = 0; k < 8; k++) c.ph[k] = 0;\n  const long long tstart_ = clock64();\n  c.tph = tstart_;\n#endif\n"
+             "  for (int k = threadIdx.x; k < TC_NCONST; k += TC_BLOCK) c.m[tc_const_addr[k]] = tc_consts[k];\n"
+             "  if (threadIdx.x == 0) c.m[0] = 0.0;\n"
+             "  __syncthreads();\n"
+             "  int st = 0, it = 0;\n"
+             "  ipmPD_CSsolver(c, mu0, maxIter, ae0, ae1, &st, &it);\n"
+             f"  {cls}_getOutputs(c, {gargs});\n"
+             f"  for (int j = threadIdx.x; j < TC_NOUT; j += TC_BLOCK) {{ const int a = tc_code[{cs['out_off']} + j]; "
+             "O[(long)j * B + tid] = TCL_LD(a); }\n"
+             "  if (threadIdx.x == 0) { status[tid] = st; iter[tid] = it; }\n"
+             "#ifdef TC_STATS\n  if (dbg && threadIdx.x == 0) {\n"
+             "    dbg[(long)(2 * TC_NGROUPS) * B + tid] = (double)(clock64() - tstart_);\n"
+             "    dbg[(long)(2 * TC_NGROUPS + 1) * B + tid] = (double)c.nMinF;\n"
+             "    for (int k = 0; k < 8; k++) dbg[(long)(2 * TC_NGROUPS + 2 + k) * B + tid] = (double)c.ph[k];\n  }\n#endif\n}\n\n"
+             "// no probe entry points in this back-end (storage is shared by life time)\n"
+             "extern \"C\" __global__ void __launch_bounds__(TC_BLOCK)\n"
+             "tc_probe_kernel(const double *__restrict__ S, const double *__restrict__ Sd, double *__restrict__ out,\n"
+             "                int which, double mu0, double ae0, double ae1, long B, double *__restrict__ Mg) {}\n\n")
+    off = 0
+    out_meta = []
+    for o in outs:
+        out_meta.append((o["name"], o["size"], len(o["ins"]), off))
+        off += len(o["ins"])
+    w.append(_class_tail(spec, T, L, out_meta, [], 1, nOut))
+    return "".join(w), L
+
+
 def _place_state_in_lds(src, T, L, spec, budget):
     """register-resident lowering: move the long-lived slots to LDS (textual: every state access of this
     lowering is MM(<constant>))"""
@@ -1528,7 +1675,7 @@ def build_class(spec, fp_contract="fast", arch="gfx950", opt="-O3", block=64, fo
                 outdir=None, stats=False, tag=None, extra_flags=(), roll=True, min_waves=0, lanes=1,
                 recip=False, fast_div=False, inline_max=0, reg_budget=150, scratch="auto", body="code",
                 waves=1, fuse=False, static_clean=False, forward=False, rcache=0, lds_state=0, share=False,
-                branch_free_tails=True, exact=False, stg_blocks=0):
+                branch_free_tails=True, exact=False, stg_blocks=0, lds_slots=20000):
     """Emit <cls>.hip (+ <cls>.h, <cls>.tape) and compile lib<cls>.so with hipcc for gfx950.
     Mirrors the createGateway/compile step of cmex2optimizeCS.m:403-417."""
     from .tapeio import save_tape
@@ -1536,7 +1683,12 @@ def build_class(spec, fp_contract="fast", arch="gfx950", opt="-O3", block=64, fo
     outdir = outdir or os.path.join(spec.folder, f"@{cls}")
     os.makedirs(outdir, exist_ok=True)
     suffix = f"_{tag}" if tag else ""
-    src, L = emit_class(spec, fp_contract=fp_contract, block=block, stats=stats, roll=roll,
+    if body == "ldsm":
+        if fp_contract != "off":
+            raise ValueError("body='ldsm' is a bit-exact back-end: fp_contract='off'")
+        src, L = emit_class_ldsm(spec, waves=waves, stats=stats, lds_slots=lds_slots)
+    else:
+      src, L = emit_class(spec, fp_contract=fp_contract, block=block, stats=stats, roll=roll,
                         min_waves=min_waves, lanes=lanes, recip=recip, fast_div=fast_div, inline_max=inline_max,
                         reg_budget=reg_budget, scratch=scratch, body=body, waves=waves, fuse=fuse,
                         static_clean=static_clean, forward=forward, rcache=rcache, lds_state=lds_state,
@@ -1547,6 +1699,7 @@ def build_class(spec, fp_contract="fast", arch="gfx950", opt="-O3", block=64, fo
              f"-ffp-contract={fp_contract}", "-I", CSRC, "-I", INCLUDE, "-Wno-unused-value"] + list(extra_flags)
     deps = [os.path.join(CSRC, "ipm_newton.hip.inc"), os.path.join(CSRC, "tc_runtime.hip.inc"),
             os.path.join(CSRC, "tc_wave.hip.inc"), os.path.join(CSRC, "tc_interp.hip.inc"),
+            os.path.join(CSRC, "tc_ldsm.hip.inc"),
             os.path.join(INCLUDE, "tenscalc_hip.h")]
     h = hashlib.sha256((src + " ".join(flags)).encode())
     for d in deps:

@@ -1,0 +1,378 @@
+"""LDS-resident tape machine (body="ldsm"): storage map and record stream.
+
+One problem instance per workgroup; its hot state lives in the CU's LDS for the whole solve and the lanes of
+the workgroup execute DIFFERENT scalar instructions of the same instance (csrc/tc_ldsm.hip.inc).  This is
+the back-end for few, large instances -- mpc_quadcopter: 1406x1406 KKT, 67 k instructions, nnz(L) 8 668 --
+where one thread per instance (body="interp") leaves the chip empty, pays an HBM round trip per level of
+the factorisation and lets the slowest of 64 instances hold a whole wavefront.  The elimination order, the
+levels of the symbolic LDL (/root/reference/lib/@csparse/sparsity_ldl.m:161-222) and of the triangular solves
+(sparsity_mldivide_l1.m:73-101, _u1.m:185-217) are fixed here, at code-generation time.
+
+Storage.  A scalar instruction's value needs a slot only while something may still read it:
+  * internal sets (primal / dual variables, mu, step lengths) and constants: a slot of their own;
+  * values of a dependency group that another group or an entry point reads ("exported"): one block per
+    group, packed by life time over one pass of the Newton loop (Lowering._assign_shared_slots, the analysis
+    the printed-code back-ends use for their LDS slots, at group granularity);
+  * values only their own group reads ("local": the L*D products of the factorisation, partial terms): dead as
+    soon as the group has been evaluated -- all groups share ONE scratch region.
+The whole state of the large problems (25-40 k doubles) does not fit the 160 KB of a CU, so addresses are split:
+[0, nLds) is LDS, [nLds, nLds+nGlob) a per-instance array in HBM whose first entries are the instance's inputs.
+Blocks are ranked by how much DEEP code (groups with many dependent levels: the factorisation, the triangular
+solves) touches them per slot; the best ranked fill the LDS, the rest -- written and read by wide, shallow
+levels whose loads overlap -- stay in HBM.
+
+Stream.  Per dependency group the instructions are level-scheduled (as interp_schedule does); the instructions
+of one level are cut into RECORDS of up to 64 (one per lane) of the same shape.  A record is a header
+(8 words: opcode | kind<<8, n, aux, count, body offset, flags, lane-array length, 0) in a contiguous header
+table -- walked with scalar loads -- plus a body of lane arrays in the code array: dest[cnt], operand_j[cnt] for
+j < n (kind SHORT, n <= 8) or dest[cnt], len[cnt], operand_k[cnt] for k < max len (kind LONG: every lane walks its
+own operand list, strictly left to right).  Operand words are address*2+neg (neg: the operand's sign in I_sum).
+"""
+from __future__ import annotations
+
+import numpy as np
+
+from . import instructions as I
+
+LANES = 64
+NSHORT = 8            # operands of a SHORT record
+K_SHORT, K_LONG, K_BARRIER = 1, 0, 2
+OP_COPY = 60
+F_GLOBAL_SRC, F_GLOBAL_DST, F_NEW_LEVEL = 1, 2, 4
+_DOT_SKIP = {I.I_minus_dot: 0, I.I_minus_dot_div: 1, I.I_plus_minus_dot: 1, I.I_plus_minus_dot_div: 2}
+_LONG_OPS = {I.I_sum, I.I_sumprod, I.I_plus_sqr, I.I_plus_abs, I.I_min, I.I_min0, I.I_max, I.I_max0,
+             I.I_max_abs, I.I_clp, I.I_minus_dot, I.I_minus_dot_div, I.I_plus_minus_dot, I.I_plus_minus_dot_div}
+DEEP = 16             # a group with at least this many dependent levels is latency critical
+
+
+def group_levels(T):
+    """-> (level of every instruction inside its group [n+1], number of levels per group [nGroups+1])"""
+    opl, ost = T.ops.tolist(), T.opStart.tolist()
+    grp = T.group.tolist()
+    lvl = [0] * (T.n + 1)
+    nlev = [0] * (T.nGroups + 1)
+    for g, members in enumerate(T.groups, 1):
+        mx = -1
+        for i in members.tolist():
+            l_ = 0
+            for j in opl[ost[i - 1]:ost[i]]:
+                if grp[j] == g and lvl[j] + 1 > l_:
+                    l_ = lvl[j] + 1
+            lvl[i] = l_
+            if l_ > mx:
+                mx = l_
+        nlev[g] = mx + 1
+    return lvl, nlev
+
+
+def assign_slots(T, defines, lds_slots=20000):
+    """-> dict(addr=int array [n+1] (-1: no storage), nLds, nGlob, nExt, consts=[(addr, value)],
+    inputs=[(first global index, numel, entry name)], dummy=LDS slot nobody reads, ...)"""
+    from .lowering import Lowering
+    L = Lowering(T, None, roll=False, lanes=1, spill_all=True)
+    n = T.n
+    grp = T.group
+    opl, ost = T.ops.tolist(), T.opStart.tolist()
+    lvl, nlev = group_levels(T)
+    read_other = np.zeros(n + 1, dtype=bool)
+    read_any = np.zeros(n + 1, dtype=bool)
+    heat = np.zeros(n + 1)                       # reads by deep groups
+    for i in range(1, n + 1):
+        if not T.used[i]:
+            continue
+        gi = int(grp[i])
+        deep = gi > 0 and nlev[gi] >= DEEP
+        for j in opl[ost[i - 1]:ost[i]]:
+            read_any[j] = True
+            if grp[j] != gi:
+                read_other[j] = True
+            if deep:
+                heat[j] += 1
+        if deep:
+            heat[i] += 1                         # written by a deep group
+    direct = L.out_needed                      # read by a get / copy source
+    # ---- requests -------------------------------------------------------------------------------------------
+    where = np.full(n + 1, -1, dtype=np.int64)   # final address
+    inputs, nExt = [], 0
+    gslot = {}                                   # instruction -> global index
+    for e in T.sets:
+        if e["external"]:
+            ins = [int(i) for i in e["ins"]]
+            for q, i in enumerate(ins):
+                gslot[i] = nExt + q
+            inputs.append((nExt, len(ins), e["name"]))
+            nExt += len(ins)
+    lds = 0
+    dummy = lds
+    lds += 1
+    zero = lds                                   # always 0.0: padding operand
+    lds += 1
+    consts = [(zero, 0.0)]
+    for i in range(1, n + 1):
+        if T.isload[i - 1] and (read_any[i] or direct[i]):
+            where[i] = lds
+            consts.append((lds, float(T.pars[T.parStart[i - 1]])))
+            lds += 1
+    for i in range(1, n + 1):                    # internal sets / copy destinations: the iterate, mu, alphas
+        if T.isset[i - 1] and i not in gslot and (read_any[i] or direct[i]):
+            where[i] = lds
+            lds += 1
+    # exported values: one block per group, packed by life time; locals: one shared scratch region
+    blocks, locals_ = [], {}
+    for g, members in enumerate(T.groups, 1):
+        ex, lo = [], []
+        for i in members.tolist():
+            if T.used[i]:
+                (ex if (read_other[i] or direct[i]) else lo).append(i)
+        if ex:
+            blocks.append(ex)
+        locals_[g] = lo
+    nLocal = max([len(v) for v in locals_.values()], default=0)
+    local_base = lds
+    lds += nLocal
+    for g, lo in locals_.items():
+        for q, i in enumerate(lo):
+            where[i] = local_base + q
+    # hot blocks into what is left of the LDS (each packed among themselves by life time), cold blocks to HBM
+    L.share = defines
+    L.ignore_dead_readers = True
+    order = sorted(range(len(blocks)), key=lambda b: -float(np.mean(heat[blocks[b]])))
+    hot, cold = [], []
+    room = int(lds_slots) - lds
+    if room < 0:
+        raise ValueError("ldsm: persistent state + local scratch (%d slots) exceed the LDS budget" % lds)
+
+    def packed(bl):
+        if not bl:
+            return 0, None
+        ps = np.full(n + 1, -1, dtype=np.int64)
+        return L._assign_shared_slots([blocks[b] for b in bl], ps), ps
+    # largest prefix of the ranking that fits (packing is not monotone in general: check each candidate size)
+    lo_, hi_ = 0, len(order)
+    best = (0, None)
+    while lo_ < hi_:
+        mid = (lo_ + hi_ + 1) // 2
+        sz, ps = packed(order[:mid])
+        if sz <= room:
+            lo_, best = mid, (sz, ps)
+        else:
+            hi_ = mid - 1
+    hot, cold = order[:lo_], order[lo_:]
+    nHot, ps = best
+    for b in hot:
+        for i in blocks[b]:
+            where[i] = lds + ps[i]
+    lds += nHot
+    nLds = lds
+    nCold, ps = packed(cold)
+    for b in cold:
+        for i in blocks[b]:
+            where[i] = nLds + nExt + ps[i]
+    for i, q in gslot.items():
+        where[i] = nLds + q
+    return dict(addr=where, nLds=nLds, nGlob=nExt + nCold, nExt=nExt, consts=consts, inputs=inputs, dummy=dummy,
+                zero=zero, nLocal=nLocal, nHot=nHot, nCold=nCold, hot_blocks=len(hot), cold_blocks=len(cold),
+                lowering=L, levels=lvl, nlev=nlev)
+
+
+# ---------------------------------------------------------------------------------------------------------------
+def _rec(words, headers, op, kind, n, aux, items, nLds, new_level):
+    """one record: items = [(dest addr, [operand words])] (<= 64, same shape for SHORT)"""
+    cnt = len(items)
+    cn = -(-cnt // 8) * 8
+    flags = F_NEW_LEVEL if new_level else 0
+    if any((w >> 1) >= nLds for _, a in items for w in a):
+        flags |= F_GLOBAL_SRC
+    if any(d >= nLds for d, _ in items):
+        flags |= F_GLOBAL_DST
+    off = len(words)
+    pad = lambda v, fill: list(v) + [fill] * (cn - len(v))        # noqa: E731
+    words += pad([d for d, _ in items], items[-1][0])
+    if kind == K_SHORT:
+        for j in range(n):
+            words += pad([a[j] for _, a in items], items[-1][1][j])
+        nn = n
+    else:
+        lens = [len(a) for _, a in items]
+        mx = max(lens)
+        words += pad(lens, 0)
+        for k in range(mx):
+            words += pad([a[k] if k < len(a) else 2 for _, a in items], 2)     # 2 = the zero slot (addr 1)
+        nn = mx
+    headers += [op | (kind << 8), nn, aux, cnt, off, flags, cn, 0]
+
+
+def build_stream(T, addr, nLds, W=1):
+    """-> dict(words, headers, granges={group: [(first header, end header)]*W}, gstats)"""
+    opl, ost = T.ops.tolist(), T.opStart.tolist()
+    types = T.types
+    lvl, nlev = group_levels(T)
+    words, headers = [], []
+    granges, gstats = {}, {}
+    for g, members in enumerate(T.groups, 1):
+        levels = {}
+        for i in members.tolist():
+            if T.used[i]:
+                levels.setdefault(lvl[i], []).append(i)
+        streams = [[] for _ in range(W)]
+        for l_ in sorted(levels):
+            short, long_ = {}, {}
+            for i in levels[l_]:
+                op = int(types[i - 1])
+                ops = opl[ost[i - 1]:ost[i]]
+                par = T.pars[T.parStart[i - 1]:T.parStart[i]]
+                aux = 0
+                if op == I.I_sum:
+                    a = [int(addr[j]) * 2 + (0 if p > 0 else 1) for j, p in zip(ops, par)]
+                elif op == I.I_sumprod:
+                    aux = int(par[0])
+                    a = [int(addr[j]) * 2 for j in ops]
+                elif op >= I.I_componentwise or op in (I.I_set, I.I_load):
+                    raise NotImplementedError(f"ldsm back-end: opcode {I.NAMES.get(op, op)}")
+                else:
+                    a = [int(addr[j]) * 2 for j in ops]
+                if min(a, default=0) < 0 or addr[i] < 0:
+                    raise AssertionError(f"instruction {i}: operand or result without storage")
+                d = int(addr[i])
+                if not a:
+                    a = [d * 2]
+                if len(a) <= NSHORT:
+                    short.setdefault((op, len(a), aux), []).append((d, a))
+                else:
+                    if op not in _LONG_OPS:
+                        raise NotImplementedError(f"ldsm back-end: {len(a)} operands for opcode {I.NAMES.get(op, op)}")
+                    long_.setdefault((op, aux), []).append((d, a))
+            recs = []                       # (cost, op, kind, n, aux, items)
+            for (op, nn, aux), items in sorted(short.items()):
+                for k0 in range(0, len(items), LANES):
+                    part = items[k0:k0 + LANES]
+                    recs.append((nn + 6, op, K_SHORT, nn, aux, part))
+            for (op, aux), items in sorted(long_.items()):
+                items = sorted(items, key=lambda it: -len(it[1]))      # similar lengths share a record
+                for k0 in range(0, len(items), LANES):
+                    part = items[k0:k0 + LANES]
+                    recs.append((len(part[0][1]) + 8, op, K_LONG, 0, aux, part))
+            # spread over the waves: longest first onto the least loaded
+            load = [0] * W
+            per = [[] for _ in range(W)]
+            for r in sorted(recs, key=lambda r: -r[0]):
+                k = load.index(min(load))
+                load[k] += r[0]
+                per[k].append(r)
+            for k in range(W):
+                first = True
+                for _, op, kind, nn, aux, part in per[k]:
+                    streams[k].append((op, kind, nn, aux, part, first))
+                    first = False
+                if W > 1:
+                    streams[k].append(None)                 # barrier: end of the level
+        rg = []
+        for k in range(W):
+            h0 = len(headers) // 8
+            for r in streams[k]:
+                if r is None:
+                    headers += [K_BARRIER << 8, 0, 0, 0, 0, F_NEW_LEVEL, 0, 0]
+                else:
+                    op, kind, nn, aux, part, first = r
+                    _rec(words, headers, op, kind, nn, aux, part, nLds, first)
+            rg.append((h0, len(headers) // 8))
+        granges[g] = rg
+        gstats[g] = (len(members), len(levels))
+    return dict(words=words, headers=headers, granges=granges, gstats=gstats)
+
+
+def copy_records(words, headers, pairs, nLds, W=1):
+    """dest <- source for a copy entry point (pairs of addresses) -> [(first header, end header)]*W"""
+    items = [(int(d), [int(s) * 2]) for d, s in pairs]
+    rg = []
+    if set(d for d, _ in items) & set(a[0] >> 1 for _, a in items):
+        chunks = [[it] for it in items]           # keep the sequential element-by-element meaning
+        chunks = [chunks] + [[] for _ in range(W - 1)]
+        seq = True
+    else:
+        recs = [items[k0:k0 + LANES] for k0 in range(0, len(items), LANES)]
+        chunks = [recs[k::W] for k in range(W)]
+        seq = False
+    for k in range(W):
+        h0 = len(headers) // 8
+        for part in chunks[k]:
+            _rec(words, headers, OP_COPY, K_SHORT, 1, 0, part, nLds, seq)
+        if W > 1:
+            headers += [K_BARRIER << 8, 0, 0, 0, 0, F_NEW_LEVEL, 0, 0]
+        rg.append((h0, len(headers) // 8))
+    return rg
+
+
+def class_stream(T, classname, defines, W=1, lds_slots=20000):
+    """everything the device walk needs for one class"""
+    sl = assign_slots(T, defines, lds_slots)
+    addr, nLds = sl["addr"], sl["nLds"]
+    st = build_stream(T, addr, nLds, W)
+    words, headers = st["words"], st["headers"]
+    rid, table = {}, []
+    for g in sorted(st["granges"]):
+        rid[g] = len(table) // (2 * W)
+        table += [x for se in st["granges"][g] for x in se]
+    for e in T.copies:
+        pairs = [(addr[d], addr[s_]) for d, s_ in zip(e["dst"], e["src"]) if addr[d] >= 0]
+        if any(a < 0 for _, a in pairs):
+            raise AssertionError("copy source without storage")
+        rg = copy_records(words, headers, pairs, nLds, W)
+        rid[e["name"]] = len(table) // (2 * W)
+        table += [x for se in rg for x in se]
+    go = T.entry(f"{classname}_getOutputs")[2]
+    out_addr = [int(addr[i]) for o in go["outputs"] for i in o["ins"]]
+    if out_addr and min(out_addr) < 0:
+        raise AssertionError("output without storage")
+    out_off = len(words)
+    words += out_addr + [0] * (-len(out_addr) % 8)
+    validate(words, headers, table, W, nLds, nLds + sl["nGlob"])
+    return dict(sl, words=words, headers=headers, rid=rid, table=table, out_off=out_off, nOut=len(out_addr),
+                gstats=st["gstats"], W=W)
+
+
+def validate(words, headers, table, W, nLds, nAddr):
+    """every address a lane would touch is inside [0, nAddr); ranges end on header boundaries; the waves sharing a
+    range meet the same number of barriers"""
+    nh = len(headers) // 8
+    for r0 in range(0, len(table), 2 * W):
+        bars = set()
+        for k in range(W):
+            h0, h1 = table[r0 + 2 * k], table[r0 + 2 * k + 1]
+            if not (0 <= h0 <= h1 <= nh):
+                raise AssertionError("bad header range")
+            nb = 0
+            for h in range(h0, h1):
+                w0, n, aux, cnt, off, flags, cn, _ = headers[8 * h:8 * h + 8]
+                kind = w0 >> 8
+                if kind == K_BARRIER:
+                    nb += 1
+                    continue
+                if not (1 <= cnt <= LANES and cn % 8 == 0 and cnt <= cn):
+                    raise AssertionError("bad record count")
+                na = 1 + n if kind == K_SHORT else 2 + n
+                if off < 0 or off + na * cn > len(words):
+                    raise AssertionError("record body outside the code array")
+                body = np.asarray(words[off:off + na * cn]).reshape(na, cn)
+                dst = body[0]
+                ops = body[1:1 + n] >> 1 if kind == K_SHORT else body[2:2 + n] >> 1
+                if dst.min() < 0 or dst.max() >= nAddr or ops.min() < 0 or ops.max() >= nAddr:
+                    raise AssertionError("address outside the state")
+                if kind == K_SHORT and not (1 <= n <= NSHORT):
+                    raise AssertionError("bad short record")
+                if kind == K_LONG and (body[1].max() > n or body[1][:cnt].min() < 1):
+                    raise AssertionError("bad long record")
+                gsrc = bool((ops >= nLds).any())
+                gdst = bool((dst >= nLds).any())
+                if gsrc != bool(flags & F_GLOBAL_SRC) or gdst != bool(flags & F_GLOBAL_DST):
+                    raise AssertionError("global flags do not match the addresses")
+            bars.add(nb)
+        if len(bars) > 1:
+            raise AssertionError("waves of one range do not meet the same number of barriers")
+
+
+def as_array(words):
+    a = np.asarray(words, dtype=np.int64)
+    if a.size and (a.max() >= 2 ** 31 or a.min() < -2 ** 31):
+        raise OverflowError("stream word out of int32 range")
+    return a.astype(np.int32)

@@ -416,12 +416,26 @@ class Lowering:
             p_, q_ = loops[k]
             return g in volatile[k] and not any(p_ <= t < q_ + 1 for t in direct.get(i, []))
 
+        # groups that no entry point the class ever calls depends on (gets that exist for the probe kernel only:
+        # getGrad__, getJ__, getHessInertia__ when useInertia=0, ...).  Classes built with sharing have no probe
+        # kernel, so a reader in such a group never runs; opt-in (ignore_dead_readers) because it changes the
+        # packing of classes whose occupancy was tuned with the conservative rule
+        dead = set()
+        if getattr(self, "ignore_dead_readers", False):
+            alive = set()
+            for e in list(T.gets) + list(T.copies):
+                if e["name"] in tl["time"] or e["name"].endswith("_getOutputs"):
+                    alive |= set(e["parents"])
+            dead = set(range(1, T.nGroups + 1)) - alive
+
         def life(i):
             g = int(grp[i])
             if g == 0 or g in keep or (g not in transient and not once(i)):
                 return None
             ts = list(Epos.get(g, [T_end]))
             for r in readers.get(i, []):
+                if int(grp[r]) in dead:
+                    continue
                 ts += Epos.get(int(grp[r]), [T_end])
             ts += direct.get(i, [])
             # the initialisation sequence (position -1) is an epoch of its own: what it computes and the loop
@@ -451,6 +465,8 @@ class Lowering:
                 req.append((blk, True, -INF, INF))
             else:
                 req.append((blk, any(x[0] for x in lives), min(x[1] for x in lives), max(x[2] for x in lives)))
+
+        self._last_req = req                 # diagnostics (scripts, tests): (block, init, first, last) per block
 
         def pack(order):
             placed, where_of, size = [], {}, 0           # placed: (first slot, size, init, a, b)
