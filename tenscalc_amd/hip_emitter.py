@@ -1453,13 +1453,20 @@ def emit_class_ldsm(spec, waves=4, stats=False, lds_slots=20000):
              "static __device__ __forceinline__ double tc_max(double a, double x) { return (a < x) ? x : a; }\n"
              "static __device__ __forceinline__ double tc_clp(double a, double x, double dx) {\n"
              "  if (dx < 0) { const double t = -x / dx; if (a > t) a = t; }\n  return a;\n}\n\n")
-    arr = lsch.as_array(cs["words"] + [0] * 64)
+    arr = lsch.as_array(cs["words"] + [0] * 1024)    # the body prefetch reads up to 12 rows of 64 past a record
     w.append(f"// the tape as data: {arr.size} body words, {len(cs['headers']) // 8} record headers\n"
              "static __device__ const int tc_code[] __attribute__((aligned(64))) = {\n")
     for k0 in range(0, arr.size, 32):
         w.append(",".join(str(int(x)) for x in arr[k0:k0 + 32]) + ",\n")
-    harr = lsch.as_array(cs["headers"] + [0] * 16)
-    w.append("};\nstatic __device__ const int tc_hdr[] __attribute__((aligned(64))) = {\n")
+    # header fields structure-of-arrays: [w0, n, aux, count, body offset, flags | cn << 8][record]
+    hd = np.asarray(cs["headers"], dtype=np.int64).reshape(-1, 8)
+    nrec = max(1, hd.shape[0])
+    hf = np.zeros((6, nrec), dtype=np.int64)
+    if hd.shape[0]:
+        hf[0], hf[1], hf[2], hf[3], hf[4] = hd[:, 0], hd[:, 1], hd[:, 2], hd[:, 3], hd[:, 4]
+        hf[5] = hd[:, 5] | (hd[:, 6] << 8)
+    harr = lsch.as_array(list(hf.reshape(-1)))
+    w.append(f"}};\n#define TC_NREC {nrec}\nstatic __device__ const int tc_hf[] __attribute__((aligned(64))) = {{\n")
     for k0 in range(0, harr.size, 32):
         w.append(",".join(str(int(x)) for x in harr[k0:k0 + 32]) + ",\n")
     w.append("};\nstatic __device__ const int tc_rng[] __attribute__((aligned(64))) = {"
@@ -1471,9 +1478,23 @@ def emit_class_ldsm(spec, waves=4, stats=False, lds_slots=20000):
     for g, members in enumerate(T.groups, 1):
         w.append(f"// group {g}: {len(members)} instructions in {cs['gstats'][g][1]} levels, {int(T.flops[g].sum())} flops\n"
                  f"#define TC_CALL_GRP{g} tc_ldsm_run(c.m, c.gm, {cs['rid'][g]})\n")
-    w.append("\n#define TC_EVAL(g) do { c.st[((g)-1)>>6] |= 1ull << (((g)-1)&63); TC_CALL_GRP##g; } while (0)\n"
-             "#define TC_NEED(g) do { if (!((c.st[((g)-1)>>6] >> (((g)-1)&63)) & 1ull)) { "
-             "c.st[((g)-1)>>6] |= 1ull << (((g)-1)&63); TC_CALL_GRP##g; } } while (0)\n")
+    w.append("\n// lazy evaluation (writeCfunctionpergroup.m:44,653-657) of the groups in a parent mask, lowest group first: a loop\n"
+             "// over the dirty bits instead of one flag test + call site per parent (record range of group g = g-1)\n"
+             "static __device__ __forceinline__ void tc_need_mask(TcCtx &c, const int wd, unsigned long long parents) {\n"
+             "  unsigned long long m = parents & ~c.st[wd];\n"
+             "  while (m) {\n    const int b = __builtin_ctzll(m);\n    m &= m - 1;\n    c.st[wd] |= 1ull << b;\n"
+             "#if defined(TC_STATS) && TC_STATS == 1\n    const long long t0_ = clock64();\n#endif\n"
+             "    tc_ldsm_run(c.m, c.gm, wd * 64 + b);\n"
+             "#if defined(TC_STATS) && TC_STATS == 1\n    c.cyc[wd * 64 + b] += clock64() - t0_;\n    c.cnt[wd * 64 + b]++;\n#endif\n"
+             "  }\n}\n")
+
+    def need(parents):
+        s_ = ""
+        for wd in range(nW):
+            m = sum(1 << ((g - 1) % 64) for g in parents if (g - 1) // 64 == wd)
+            if m:
+                s_ += f"  tc_need_mask(c, {wd}, 0x{m:x}ull);\n"
+        return s_
 
     def inval(children):
         s_ = ""
@@ -1501,8 +1522,7 @@ def emit_class_ldsm(spec, waves=4, stats=False, lds_slots=20000):
     for e in T.gets:
         args = ", ".join(f"double *y{k + 1}" for k in range(len(e["outputs"])))
         w.append(f"static __device__ __forceinline__ void {e['name']}(TcCtx &c, {args}) {{\n")
-        for g in e["parents"]:
-            w.append(f"  TC_NEED({g});\n")
+        w.append(need(e["parents"]))
         if e["name"].endswith("_getOutputs"):
             w.append("  tc_block_sync();\n}\n")      # the kernel gathers the outputs itself
             continue
@@ -1513,8 +1533,7 @@ def emit_class_ldsm(spec, waves=4, stats=False, lds_slots=20000):
         w.append("}\n")
     for e in T.copies:
         w.append(f"static __device__ __forceinline__ void {e['name']}(TcCtx &c) {{\n")
-        for g in e["parents"]:
-            w.append(f"  TC_NEED({g});\n")
+        w.append(need(e["parents"]))
         w.append(f"  tc_ldsm_run(c.m, c.gm, {cs['rid'][e['name']]});\n" + inval(e["children"]) + "}\n")
     w.append("\n#define TC_POW_HALF(x) sqrt(x)\n#include \"ipm_newton.hip.inc\"\n\n")
     outs = T.entry(f"{cls}_getOutputs")[2]["outputs"]
@@ -1539,6 +1558,8 @@ def emit_class_ldsm(spec, waves=4, stats=False, lds_slots=20000):
              "O[(long)j * B + tid] = TCL_LD(a); }\n"
              "  if (threadIdx.x == 0) { status[tid] = st; iter[tid] = it; }\n"
              "#ifdef TC_STATS\n  if (dbg && threadIdx.x == 0) {\n"
+             "    for (int k = 0; k < TC_NGROUPS; k++) {\n"
+             "      dbg[(long)k * B + tid] = (double)c.cyc[k];\n      dbg[(long)(TC_NGROUPS + k) * B + tid] = (double)c.cnt[k];\n    }\n"
              "    dbg[(long)(2 * TC_NGROUPS) * B + tid] = (double)(clock64() - tstart_);\n"
              "    dbg[(long)(2 * TC_NGROUPS + 1) * B + tid] = (double)c.nMinF;\n"
              "    for (int k = 0; k < 8; k++) dbg[(long)(2 * TC_NGROUPS + 2 + k) * B + tid] = (double)c.ph[k];\n  }\n#endif\n}\n\n"

@@ -25,8 +25,9 @@ Stream.  Per dependency group the instructions are level-scheduled (as interp_sc
 of one level are cut into RECORDS of up to 64 (one per lane) of the same shape.  A record is a header
 (8 words: opcode | kind<<8, n, aux, count, body offset, flags, lane-array length, 0) in a contiguous header
 table -- walked with scalar loads -- plus a body of lane arrays in the code array: dest[cnt], operand_j[cnt] for
-j < n (kind SHORT, n <= 8) or dest[cnt], len[cnt], operand_k[cnt] for k < max len (kind LONG: every lane walks its
-own operand list, strictly left to right).  Operand words are address*2+neg (neg: the operand's sign in I_sum).
+j < n (kind SHORT, n <= 8) or dest[cnt], len[cnt], head0[cnt], head1[cnt], word_k[cnt] for k < max len rounded up
+to 8 (kind LONG: every lane walks its own operand list, strictly left to right; head0/1 = the leading non-product
+operands of the dot opcodes).  Operand words are address*2+neg (neg: the operand's sign in I_sum).
 """
 from __future__ import annotations
 
@@ -36,8 +37,11 @@ from . import instructions as I
 
 LANES = 64
 NSHORT = 8            # operands of a SHORT record
-K_SHORT, K_LONG, K_BARRIER = 1, 0, 2
+K_SHORT, K_LONG, K_BARRIER, K_FOLD = 1, 0, 2, 3
 OP_COPY = 60
+OP_CLPTERM = 61       # (b < 0) ? -a/b : DBL_MAX  -- one term of I_clp
+F_SUM = 3             # fold opcodes of K_FOLD records (the dot opcodes and I_sumprod keep their own number)
+STAGE = 2048          # staging slots for the terms of long instructions
 F_GLOBAL_SRC, F_GLOBAL_DST, F_NEW_LEVEL = 1, 2, 4
 _DOT_SKIP = {I.I_minus_dot: 0, I.I_minus_dot_div: 1, I.I_plus_minus_dot: 1, I.I_plus_minus_dot_div: 2}
 _LONG_OPS = {I.I_sum, I.I_sumprod, I.I_plus_sqr, I.I_plus_abs, I.I_min, I.I_min0, I.I_max, I.I_max0,
@@ -65,7 +69,7 @@ def group_levels(T):
     return lvl, nlev
 
 
-def assign_slots(T, defines, lds_slots=20000):
+def assign_slots(T, defines, lds_slots=20000, stage=STAGE):
     """-> dict(addr=int array [n+1] (-1: no storage), nLds, nGlob, nExt, consts=[(addr, value)],
     inputs=[(first global index, numel, entry name)], dummy=LDS slot nobody reads, ...)"""
     from .lowering import Lowering
@@ -130,6 +134,8 @@ def assign_slots(T, defines, lds_slots=20000):
     nLocal = max([len(v) for v in locals_.values()], default=0)
     local_base = lds
     lds += nLocal
+    stage_base = lds                             # terms of long instructions (build_stream), + 8: chunked reads
+    lds += int(stage) + 8
     for g, lo in locals_.items():
         for q, i in enumerate(lo):
             where[i] = local_base + q
@@ -171,7 +177,7 @@ def assign_slots(T, defines, lds_slots=20000):
     for i, q in gslot.items():
         where[i] = nLds + q
     return dict(addr=where, nLds=nLds, nGlob=nExt + nCold, nExt=nExt, consts=consts, inputs=inputs, dummy=dummy,
-                zero=zero, nLocal=nLocal, nHot=nHot, nCold=nCold, hot_blocks=len(hot), cold_blocks=len(cold),
+                zero=zero, stage_base=stage_base, nStage=int(stage), nLocal=nLocal, nHot=nHot, nCold=nCold, hot_blocks=len(hot), cold_blocks=len(cold),
                 lowering=L, levels=lvl, nlev=nlev)
 
 
@@ -192,18 +198,46 @@ def _rec(words, headers, op, kind, n, aux, items, nLds, new_level):
         for j in range(n):
             words += pad([a[j] for _, a in items], items[-1][1][j])
         nn = n
+    elif kind == K_FOLD:                                     # items: (dest, [len, head0, head1, base])
+        for j in range(4):
+            words += pad([a[j] for _, a in items], items[-1][1][j])
+        nn = -(-max(a[0] for _, a in items) // 8) * 8
+        flags &= ~F_GLOBAL_SRC
+        if any((a[j] >> 1) >= nLds for _, a in items for j in (1, 2)):
+            flags |= F_GLOBAL_SRC
     else:
-        lens = [len(a) for _, a in items]
-        mx = max(lens)
+        skip = _DOT_SKIP.get(op, 0)
+        lens = [len(a) - skip for _, a in items]
+        mx = -(-max(lens) // 8) * 8
         words += pad(lens, 0)
+        for q in range(2):                                  # heads of the dot opcodes (zero slot when unused)
+            words += pad([a[q] if q < skip else 2 for _, a in items], 2)
         for k in range(mx):
-            words += pad([a[k] if k < len(a) else 2 for _, a in items], 2)     # 2 = the zero slot (addr 1)
+            words += pad([a[skip + k] if skip + k < len(a) else 2 for _, a in items], 2)     # 2 = the zero slot (addr 1)
         nn = mx
     headers += [op | (kind << 8), nn, aux, cnt, off, flags, cn, 0]
 
 
-def build_stream(T, addr, nLds, W=1):
-    """-> dict(words, headers, granges={group: [(first header, end header)]*W}, gstats)"""
+_TERM = {  # long instruction -> (term opcode, operands per term, fold opcode); terms are evaluated in parallel, one per
+    # lane, into consecutive staging slots; ONE lane then folds them strictly left to right
+    I.I_minus_dot: ("prod", 2, I.I_minus_dot), I.I_minus_dot_div: ("prod", 2, I.I_minus_dot_div),
+    I.I_plus_minus_dot: ("prod", 2, I.I_plus_minus_dot), I.I_plus_minus_dot_div: ("prod", 2, I.I_plus_minus_dot_div),
+    I.I_plus_sqr: (I.I_sqr, 1, F_SUM), I.I_plus_abs: (I.I_abs, 1, F_SUM), I.I_max_abs: (I.I_abs, 1, I.I_max),
+    I.I_min: (OP_COPY, 1, I.I_min), I.I_min0: (OP_COPY, 1, I.I_min0), I.I_max: (OP_COPY, 1, I.I_max),
+    I.I_max0: (OP_COPY, 1, I.I_max0), I.I_sum: (I.I_sum, 1, F_SUM), I.I_clp: (OP_CLPTERM, 2, I.I_clp),
+}
+
+
+def build_stream(T, addr, nLds, W=1, stage_base=None, nStage=0):
+    """-> dict(words, headers, granges={group: [(first header, end header)]*W}, gstats)
+
+    A LONG instruction (more than 8 operands: the dot products of the factorisation and of the triangular solves,
+    norms, minima over all constraints) would keep one lane busy for its whole operand list while the tape words
+    of that list trickle in.  With a staging area it is split instead: its TERMS (products, squares, quotients)
+    become short instructions of their own -- executed in parallel, one per lane, results in consecutive staging
+    slots -- and a FOLD record lets one lane add (min, max) them strictly left to right from those slots, with
+    no tape words to wait for.  Every product is rounded exactly as inside the dot (no FMA), and the fold is the
+    reference's left-to-right chain, so values do not change."""
     opl, ost = T.ops.tolist(), T.opStart.tolist()
     types = T.types
     lvl, nlev = group_levels(T)
@@ -215,8 +249,33 @@ def build_stream(T, addr, nLds, W=1):
             if T.used[i]:
                 levels.setdefault(lvl[i], []).append(i)
         streams = [[] for _ in range(W)]
+
+        def emit(recs):
+            """one step: records spread over the waves (longest first onto the least loaded), then a barrier"""
+            if not recs:
+                return
+            load = [0] * W
+            per = [[] for _ in range(W)]
+            for r in sorted(recs, key=lambda r: -r[0]):
+                k = load.index(min(load))
+                load[k] += r[0]
+                per[k].append(r)
+            for k in range(W):
+                first = True
+                for _, op, kind, nn, aux, part in per[k]:
+                    streams[k].append((op, kind, nn, aux, part, first))
+                    first = False
+                if W > 1:
+                    streams[k].append(None)                 # barrier: end of the step
+
+        def cut(groups_, kind, cost):
+            recs = []
+            for (op, nn, aux), items in sorted(groups_.items()):
+                for k0 in range(0, len(items), LANES):
+                    recs.append((cost(nn, items[k0]), op, kind, nn, aux, items[k0:k0 + LANES]))
+            return recs
         for l_ in sorted(levels):
-            short, long_ = {}, {}
+            short, long_, staged = {}, {}, []
             for i in levels[l_]:
                 op = int(types[i - 1])
                 ops = opl[ost[i - 1]:ost[i]]
@@ -238,34 +297,47 @@ def build_stream(T, addr, nLds, W=1):
                     a = [d * 2]
                 if len(a) <= NSHORT:
                     short.setdefault((op, len(a), aux), []).append((d, a))
+                    continue
+                if op not in _LONG_OPS:
+                    raise NotImplementedError(f"ldsm back-end: {len(a)} operands for opcode {I.NAMES.get(op, op)}")
+                # terms of the instruction
+                if op == I.I_sumprod:
+                    top, tn, fop = "prod", aux, I.I_sumprod
                 else:
-                    if op not in _LONG_OPS:
-                        raise NotImplementedError(f"ldsm back-end: {len(a)} operands for opcode {I.NAMES.get(op, op)}")
-                    long_.setdefault((op, aux), []).append((d, a))
-            recs = []                       # (cost, op, kind, n, aux, items)
-            for (op, nn, aux), items in sorted(short.items()):
-                for k0 in range(0, len(items), LANES):
-                    part = items[k0:k0 + LANES]
-                    recs.append((nn + 6, op, K_SHORT, nn, aux, part))
-            for (op, aux), items in sorted(long_.items()):
-                items = sorted(items, key=lambda it: -len(it[1]))      # similar lengths share a record
-                for k0 in range(0, len(items), LANES):
-                    part = items[k0:k0 + LANES]
-                    recs.append((len(part[0][1]) + 8, op, K_LONG, 0, aux, part))
-            # spread over the waves: longest first onto the least loaded
-            load = [0] * W
-            per = [[] for _ in range(W)]
-            for r in sorted(recs, key=lambda r: -r[0]):
-                k = load.index(min(load))
-                load[k] += r[0]
-                per[k].append(r)
-            for k in range(W):
-                first = True
-                for _, op, kind, nn, aux, part in per[k]:
-                    streams[k].append((op, kind, nn, aux, part, first))
-                    first = False
-                if W > 1:
-                    streams[k].append(None)                 # barrier: end of the level
+                    top, tn, fop = _TERM[op]
+                skip = _DOT_SKIP.get(op, 0)
+                nterm = (len(a) - skip) // tn
+                if nStage and tn <= NSHORT and nterm <= nStage and (len(a) - skip) % tn == 0:
+                    staged.append((op, fop, aux, d, a[:skip], top, tn, [a[skip + q * tn:skip + (q + 1) * tn] for q in range(nterm)]))
+                else:
+                    long_.setdefault((op, 0, aux), []).append((d, a))
+            recs = cut(short, K_SHORT, lambda nn, it: nn + 6)
+            for key, items in long_.items():
+                long_[key] = sorted(items, key=lambda it: -len(it[1]))      # similar lengths share a record
+            recs += cut(long_, K_LONG, lambda nn, it: len(it[1]) + 8)
+            # staged long instructions: rounds that fit the staging area; the first round's terms share the step
+            # of the level's short records
+            staged.sort(key=lambda s_: -len(s_[7]))
+            k0 = 0
+            while True:
+                terms, folds, used = {}, {}, 0
+                while k0 < len(staged) and used + len(staged[k0][7]) <= nStage:
+                    op, fop, aux, d, heads, top, tn, tl = staged[k0]
+                    base = stage_base + used
+                    for q, tw in enumerate(tl):
+                        key = (I.I_sumprod, tn, tn) if top == "prod" else (top, tn, 0)
+                        terms.setdefault(key, []).append((base + q, tw))
+                    hw = [heads[q] if q < len(heads) else 2 for q in range(2)]
+                    folds.setdefault((fop, 0, aux), []).append((d, [len(tl), hw[0], hw[1], base]))
+                    used += len(tl)
+                    k0 += 1
+                emit(recs + cut(terms, K_SHORT, lambda nn, it: nn + 6))
+                recs = []
+                for key, items in folds.items():
+                    folds[key] = sorted(items, key=lambda it: -it[1][0])
+                emit(cut(folds, K_FOLD, lambda nn, it: it[1][0] // 2 + 8))
+                if k0 >= len(staged):
+                    break
         rg = []
         for k in range(W):
             h0 = len(headers) // 8
@@ -307,7 +379,7 @@ def class_stream(T, classname, defines, W=1, lds_slots=20000):
     """everything the device walk needs for one class"""
     sl = assign_slots(T, defines, lds_slots)
     addr, nLds = sl["addr"], sl["nLds"]
-    st = build_stream(T, addr, nLds, W)
+    st = build_stream(T, addr, nLds, W, stage_base=sl["stage_base"], nStage=sl["nStage"])
     words, headers = st["words"], st["headers"]
     rid, table = {}, []
     for g in sorted(st["granges"]):
@@ -350,17 +422,23 @@ def validate(words, headers, table, W, nLds, nAddr):
                     continue
                 if not (1 <= cnt <= LANES and cn % 8 == 0 and cnt <= cn):
                     raise AssertionError("bad record count")
-                na = 1 + n if kind == K_SHORT else 2 + n
+                na = 1 + n if kind == K_SHORT else (5 if kind == K_FOLD else 4 + n)
                 if off < 0 or off + na * cn > len(words):
                     raise AssertionError("record body outside the code array")
                 body = np.asarray(words[off:off + na * cn]).reshape(na, cn)
                 dst = body[0]
-                ops = body[1:1 + n] >> 1 if kind == K_SHORT else body[2:2 + n] >> 1
+                if kind == K_FOLD:
+                    if n % 8 or body[1].max() > n or body[1][:cnt].min() < 1 or body[4].min() < 0 or \
+                            (body[4] + body[1]).max() > nLds:
+                        raise AssertionError("bad fold record")
+                    ops = body[2:4] >> 1
+                else:
+                    ops = body[1:1 + n] >> 1 if kind == K_SHORT else body[2:4 + n] >> 1
                 if dst.min() < 0 or dst.max() >= nAddr or ops.min() < 0 or ops.max() >= nAddr:
                     raise AssertionError("address outside the state")
                 if kind == K_SHORT and not (1 <= n <= NSHORT):
                     raise AssertionError("bad short record")
-                if kind == K_LONG and (body[1].max() > n or body[1][:cnt].min() < 1):
+                if kind == K_LONG and (n % 8 or body[1].max() > n or body[1][:cnt].min() < 1):
                     raise AssertionError("bad long record")
                 gsrc = bool((ops >= nLds).any())
                 gdst = bool((dst >= nLds).any())
