@@ -260,13 +260,15 @@ def build_stream(T, addr, nLds, W=1, stage_base=None, nStage=0):
                 k = load.index(min(load))
                 load[k] += r[0]
                 per[k].append(r)
+            # the barrier that ends the step must make HBM writes visible too only if the step has any
+            gdst = any(d >= nLds for r in recs for d, _ in r[5])
             for k in range(W):
                 first = True
                 for _, op, kind, nn, aux, part in per[k]:
                     streams[k].append((op, kind, nn, aux, part, first))
                     first = False
                 if W > 1:
-                    streams[k].append(None)                 # barrier: end of the step
+                    streams[k].append(("barrier", gdst))    # end of the step
 
         def cut(groups_, kind, cost):
             recs = []
@@ -342,8 +344,8 @@ def build_stream(T, addr, nLds, W=1, stage_base=None, nStage=0):
         for k in range(W):
             h0 = len(headers) // 8
             for r in streams[k]:
-                if r is None:
-                    headers += [K_BARRIER << 8, 0, 0, 0, 0, F_NEW_LEVEL, 0, 0]
+                if r[0] == "barrier":
+                    headers += [K_BARRIER << 8, 0, 0, 0, 0, F_NEW_LEVEL | (F_GLOBAL_DST if r[1] else 0), 0, 0]
                 else:
                     op, kind, nn, aux, part, first = r
                     _rec(words, headers, op, kind, nn, aux, part, nLds, first)
@@ -370,7 +372,7 @@ def copy_records(words, headers, pairs, nLds, W=1):
         for part in chunks[k]:
             _rec(words, headers, OP_COPY, K_SHORT, 1, 0, part, nLds, seq)
         if W > 1:
-            headers += [K_BARRIER << 8, 0, 0, 0, 0, F_NEW_LEVEL, 0, 0]
+            headers += [K_BARRIER << 8, 0, 0, 0, 0, F_NEW_LEVEL | F_GLOBAL_DST, 0, 0]
         rg.append((h0, len(headers) // 8))
     return rg
 

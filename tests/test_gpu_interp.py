@@ -95,6 +95,120 @@ def test_l1l2_interp_bit_exact(libs, tmp_path):
     assert np.array_equal(got, ref)
 
 
+@pytest.mark.parametrize("variant", ["sls_ldsm", "sls_ldsm4"])
+def test_sls_ldsm_bit_exact(libs, sls_spec, tmp_path, variant):
+    """LDS-resident tape machine (csrc/tc_ldsm.hip.inc): one instance per workgroup of 1 / 4 wavefronts, the lanes
+    execute different instructions, long sums split into parallel terms + an ordered fold: same bits as the oracle"""
+    from tenscalc_amd.problems.sls import SOLVE_ARGS, sls_data
+    B = 70
+    data = []
+    for k in range(B):
+        A, b, x0 = sls_data(4500 + k)
+        data.append(dict(A=A, b=b, x=x0))
+    (st, it, got), (rst, rit, ref), _ = _solve_both(sls_spec, libs[variant], data, SOLVE_ARGS, B, tmp_path, variant)
+    assert np.array_equal(st, rst) and np.array_equal(it, rit) and (st == 0).all()
+    assert np.array_equal(got, ref)
+
+
+@pytest.mark.parametrize("variant", ["dcmotor_ldsm4", "dcmotor_ldsm_cold"])
+def test_dcmotor_ldsm_bit_exact(libs, tmp_path, variant):
+    """nG > 0, second LDL; `ldsm_cold`: an LDS budget too small for the state, so part of it lives in the
+    per-instance HBM array (global operand / destination path of the device walk)"""
+    import __graft_entry__ as g
+    from tenscalc_amd.problems.mpc_dcmotor import SOLVE_ARGS, dcmotor_data, mpc_dcmotor
+    spec = mpc_dcmotor(folder=g.GENERATED)
+    B = 130
+    data = [dcmotor_data(4000 + k) for k in range(B)]
+    (st, it, got), (rst, rit, ref), _ = _solve_both(spec, libs[variant], data, SOLVE_ARGS, B, tmp_path, "dc")
+    assert np.array_equal(st, rst) and np.array_equal(it, rit) and (st == 0).all()
+    assert np.array_equal(got, ref)
+
+
+def test_l1l2_ldsm_bit_exact(libs, tmp_path):
+    """BASELINE configs[2] through the LDS machine: 25 k doubles of state, 19.7 k of them in LDS, the rest in HBM"""
+    import __graft_entry__ as g
+    from tenscalc_amd.problems.l1l2 import SOLVE_ARGS, l1l2, l1l2_data
+    spec = l1l2(folder=g.GENERATED)
+    B = 6
+    data = [l1l2_data(10 + k) for k in range(B)]
+    (st, it, got), (rst, rit, ref), _ = _solve_both(spec, libs["l1l2_ldsm4"], data, SOLVE_ARGS, B, tmp_path, "l1l2")
+    assert np.array_equal(st, rst) and np.array_equal(it, rit) and (st == 0).all()
+    assert np.array_equal(got, ref)
+
+
+def test_quadcopter_T100_ldsm_vs_interp_vs_oracle(libs, tmp_path):
+    """BASELINE configs[4] as written (T=100, 1406x1406 KKT, 67 k instructions), B = 64.
+
+    (1) The two device back-ends -- interp (one thread per instance, state in HBM) and ldsm4 (one instance per
+    workgroup, LDL factor and solves in LDS) -- evaluate the same tape with the same device libm in the same
+    operand order: status, iteration count and all 2404 outputs are BIT-IDENTICAL between them over complete
+    solves (20..371 iterations).
+    (2) Against the oracle the tolerance is on few-step quantities (device pow() and glibc's differ by 1 ulp on a
+    quarter of their arguments, and on this non-convex problem an ulp can change the path of the iteration --
+    module docstring): after maxIter = 1 Newton iteration every output agrees to 1e-8 relative to 1+|ref| (measured
+    2.6e-10); after 3 iterations a line-search branch has already flipped on some instances (0.07 on the worst), so
+    only the fraction that still agrees to 1e-6 is asserted (at least half).
+    (3) Complete solves: status 0 on every instance, thrust limits respected; where the oracle needs the same
+    number of iterations the outputs agree to 1e-6."""
+    import __graft_entry__ as g
+    from tenscalc_amd.problems.mpc_quadcopter import SOLVE_ARGS, mpc_quadcopter, quadcopter_data
+    from tenscalc_amd.tapeio import save_tape
+    from oracle.tc_oracle import Oracle
+    spec = mpc_quadcopter(folder=g.GENERATED)
+    B = 64
+    data = [quadcopter_data(20 + k) for k in range(B)]
+    names = [n for n, _ in spec.parameters + spec.variables]
+    stacked = {n: np.stack([np.asarray(d[n], dtype=float).reshape(-1, order="F") for d in data]) for n in names}
+    tape = str(tmp_path / "q.tape")
+    save_tape(spec.tape, tape)
+    c = spec.classname
+    res = {}
+    for tag in ("quadcopter_ldsm4", "quadcopter_interp"):
+        obj = _load(libs[tag], B)
+        for n in names:
+            obj.set(n, stacked[n])
+        st, it, tm = obj.solve(**SOLVE_ARGS)
+        res[tag] = (st, it, np.concatenate([a.reshape(B, -1) for a in obj.getOutputs()], axis=1), tm)
+        if tag == "quadcopter_ldsm4":
+            few = {}
+            for mi in (1, 3):
+                obj.solve(**dict(SOLVE_ARGS, maxIter=mi))
+                few[mi] = np.concatenate([a.reshape(B, -1) for a in obj.getOutputs()], axis=1)
+            out = obj.getOutputs(as_dict=True)
+        obj.close()
+    a, b = res["quadcopter_ldsm4"], res["quadcopter_interp"]
+    print("\nquadcopter T=100, B=64: ldsm4 %.0f ms, interp %.0f ms; iterations %d..%d" % (a[3] * 1e3, b[3] * 1e3, a[1].min(), a[1].max()))
+    assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1]) and np.array_equal(a[2], b[2], equal_nan=True)
+    assert (a[0] == 0).all()
+    nref = 12
+    sub = {f"{c}_set_{n}": stacked[n][:nref] for n in names}
+    o = Oracle(tape)
+    for mi in (1, 3):
+        ref, _, _ = o.solve_batch(sub, c + "_getOutputs", nref, mu0=SOLVE_ARGS["mu0"], maxIter=mi)
+        d = (np.abs(few[mi][:nref] - ref) / (1 + np.abs(ref))).max(axis=1)
+        print("after %d iteration(s): max |diff|/(1+|ref|) per instance: max %.3g, median %.3g; <= 1e-6 on %d of %d"
+              % (mi, d.max(), np.median(d), (d <= 1e-6).sum(), nref))
+        if mi == 1:
+            assert d.max() <= 1e-8
+        else:        # a line-search branch has already flipped on some instances (measured: 0.07 on the worst)
+            assert (d <= 1e-6).sum() >= nref // 2
+    ref, rst, rit = o.solve_batch(sub, c + "_getOutputs", nref, mu0=SOLVE_ARGS["mu0"], maxIter=SOLVE_ARGS["maxIter"])
+    assert (rst == 0).all()
+    same = a[1][:nref] == rit
+    print("same iteration count as the oracle on %d of %d instances" % (same.sum(), nref))
+    assert same.sum() >= nref // 3
+    np.testing.assert_allclose(a[2][:nref][same], ref[same], rtol=1e-6, atol=1e-8)
+    # the 2404 outputs of a solve: J first, then Jp2, Jv2, Jthrust, t, u, m_thrust, ...
+    m = spec.outputs
+    off = 0
+    for nm, sz in m:
+        k = int(np.prod(sz)) if len(sz) else 1
+        if nm == "m_thrust":
+            mt = a[2][:, off:off + k]
+            assert (mt >= 5 - 1e-6).all() and (mt <= 20 + 1e-6).all()       # thrust limits (mpc_quadcopter.m:121-122)
+        off += k
+
+
 def test_small_quadcopter_interp(libs, tmp_path):
     """mpc_quadcopter with an 8-step horizon: sqrt-family opcodes, equality constraints, long dot
     products.  Tolerance-based (libm pow differs between device and host, see module docstring)."""

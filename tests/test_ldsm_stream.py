@@ -1,0 +1,242 @@
+"""CPU: the record stream of the LDS-resident tape machine (tenscalc_amd/ldsm_schedule.py), walked by a Python
+model of csrc/tc_ldsm.hip.inc along the entry-point sequence of the Newton loop, reproduces the oracle's value
+of every `get` bit for bit.
+
+This pins the scheduler without a GPU: the storage map (LDS / HBM split, blocks sharing slots by life time, the
+group-local scratch region), the levels, the record packing, the split of long instructions into parallel terms
++ an ordered fold, sign bits, heads of the dot opcodes.  Storage is SHARED by life time, so the model has to
+call the entry points in the order the solver does (csrc/ipm_newton.hip.inc); the device walk itself is checked
+against the oracle in tests/test_gpu_interp.py."""
+import numpy as np
+import pytest
+
+from tenscalc_amd import instructions as I
+from tenscalc_amd import ldsm_schedule as lsch
+from test_interp_stream import _eval
+
+f64 = np.float64
+FOLD_TERM = {lsch.F_SUM: I.I_sum}
+
+
+def _fold(op, aux, xs, h0, h1):
+    """K_FOLD record: xs = the staged terms, left to right"""
+    with np.errstate(all="ignore"):
+        if op in lsch._DOT_SKIP:
+            acc = xs[0]
+            for x in xs[1:]:
+                acc = acc + x
+            return {I.I_minus_dot: lambda: -acc, I.I_minus_dot_div: lambda: -acc / h0,
+                    I.I_plus_minus_dot: lambda: h0 - acc, I.I_plus_minus_dot_div: lambda: (h0 - acc) / h1}[op]()
+        if op == I.I_sumprod:
+            total = line = None
+            nS = 0
+            for s, x in enumerate(xs):
+                line = x if line is None else line + x
+                if s + 1 < len(xs):
+                    nS += aux
+                    if nS >= 100:
+                        total = line if total is None else total + line
+                        line, nS = None, 0
+            return line if total is None else total + line
+        if op == I.I_clp:
+            acc = f64(np.finfo(float).max)
+            for x in xs:
+                if acc > x:
+                    acc = x
+            return acc
+        if op == lsch.F_SUM:
+            acc = xs[0]
+            for x in xs[1:]:
+                acc = acc + x
+            return acc
+        return _eval(op, 0, xs, [0] * len(xs))        # I_min, I_min0, I_max, I_max0
+
+
+def _term(op, aux, v, sg):
+    if op == lsch.OP_CLPTERM:
+        with np.errstate(all="ignore"):
+            return -v[0] / v[1] if v[1] < 0 else f64(np.finfo(float).max)
+    return _eval(op, aux, v, sg)
+
+
+class Machine:
+    """one instance: m[address] (LDS and HBM part in one array), lazy group flags, the record walk"""
+
+    def __init__(self, T, cs):
+        self.T, self.cs = T, cs
+        self.m = np.full(cs["nLds"] + cs["nGlob"], np.nan)
+        for a, v in cs["consts"]:
+            self.m[a] = v
+        self.m[cs["dummy"]] = 0.0
+        self.clean = set()
+        self.hd = np.asarray(cs["headers"], dtype=np.int64).reshape(-1, 8)
+        self.words = cs["words"]
+        self.W = cs["W"]
+
+    def run(self, rid):
+        tb = self.cs["table"][rid * 2 * self.W:(rid + 1) * 2 * self.W]
+        pcs = [tb[2 * k] for k in range(self.W)]
+        ends = [tb[2 * k + 1] for k in range(self.W)]
+        while any(p < e for p, e in zip(pcs, ends)):       # the waves run one at a time from barrier to barrier
+            for k in range(self.W):
+                pcs[k] = self._to_barrier(pcs[k], ends[k])
+
+    def _to_barrier(self, h, end):
+        m, w = self.m, self.words
+        while h < end:
+            w0, n, aux, cnt, off, flags, cn, _ = (int(x) for x in self.hd[h])
+            kind, op = w0 >> 8, w0 & 255
+            h += 1
+            if kind == lsch.K_BARRIER:
+                return h
+            rows = lambda j: w[off + j * cn:off + j * cn + cnt]       # noqa: E731
+            dst = rows(0)
+            res = []
+            if kind == lsch.K_SHORT:
+                cols = [rows(1 + j) for j in range(n)]
+                for q in range(cnt):                                   # all operand reads of the record first
+                    ws = [cols[j][q] for j in range(n)]
+                    res.append(_term(op, aux, [m[x >> 1] for x in ws], [x & 1 for x in ws]))
+            elif kind == lsch.K_FOLD:
+                ln, h0, h1, base = rows(1), rows(2), rows(3), rows(4)
+                for q in range(cnt):
+                    res.append(_fold(op, aux, [m[base[q] + k] for k in range(ln[q])], m[h0[q] >> 1], m[h1[q] >> 1]))
+            else:
+                ln = rows(1)
+                for q in range(cnt):
+                    ws = [w[off + (2 + j) * cn + q] for j in range(2)][:lsch._DOT_SKIP.get(op, 0)] + \
+                         [w[off + (4 + k) * cn + q] for k in range(ln[q])]
+                    res.append(_eval(op, aux, [m[x >> 1] for x in ws], [x & 1 for x in ws]))
+            for q in range(cnt):
+                m[dst[q]] = res[q]
+        return h
+
+    # entry points (writeCfunctionpergroup.m:513-852)
+    def need(self, parents):
+        for g in parents:
+            if g not in self.clean:
+                self.clean.add(g)
+                self.run(self.cs["rid"][g])
+
+    def set(self, name, values):
+        _, _, e = self.T.entry(name)
+        for i, v in zip(e["ins"], np.asarray(values, dtype=float).reshape(-1, order="F")):
+            if self.cs["addr"][i] >= 0:
+                self.m[self.cs["addr"][i]] = v
+        self.clean -= set(e["children"])
+
+    def get(self, name):
+        _, _, e = self.T.entry(name)
+        self.need(e["parents"])
+        out = []
+        for o in e["outputs"]:
+            for i in o["ins"]:
+                out.append(float(self.T.pars[self.T.parStart[i - 1]]) if self.T.isload[i - 1] else self.m[self.cs["addr"][i]])
+        return np.array(out)
+
+    def copy(self, name):
+        _, _, e = self.T.entry(name)
+        self.need(e["parents"])
+        self.run(self.cs["rid"][name])
+        self.clean -= set(e["children"])
+
+
+def _check(spec, data, tape_oracle, args, W=1, lds_slots=20000):
+    T, c, D = spec.tape, spec.classname, spec.defines
+    cs = lsch.class_stream(T, c, D, W=W, lds_slots=lds_slots)
+    o = tape_oracle(T, c)
+    mach = Machine(T, cs)
+
+    def both(kind, name, *a):
+        if kind == "get":
+            got, ref = mach.get(name), o.get(name)
+            assert got.shape == ref.shape and all(x == y or (x != x and y != y) for x, y in zip(got, ref)), \
+                f"{name}: {np.sum(got != ref)} of {ref.size} values differ from the oracle"
+            return ref
+        getattr(mach, kind)(name, *a)
+        getattr(o, kind)(name, *a)
+    for nm, _ in spec.parameters + spec.variables:
+        both("set", f"{c}_set_{nm}", data[nm])
+    ae = args.get("addEye2Hessian", (1e-9, 1e-9))
+    if D["setAddEye2Hessian"]:
+        both("set", "setAddEye2HessianU__", [ae[0]])
+        both("set", "setAddEye2HessianEq__", [ae[1]])
+    both("copy", "initPrimal__")
+    if D["scaleCost"]:
+        both("copy", "scaleCost__")
+        both("get", "getScale4Cost__")
+    mu = args["mu0"]
+    if D["nF"] > 0:
+        if D["scaleInequalities"]:
+            both("copy", "scaleIneq__")
+        both("set", "setMu__", [mu])
+        both("copy", "initDualIneq__")
+    if D["nG"] > 0:
+        both("copy", "initDualEqX__")
+    for it in range(2):                      # two passes of the loop body of csrc/ipm_newton.hip.inc
+        both("get", "getNorminf_Grad__")
+        if D["nG"] > 0:
+            both("get", "getNorminf_G__")
+        if D["nF"] > 0:
+            both("get", "getGapMinFMinLambda__")
+        both("get", "getCurvature__")
+        both("get", "getDirectionError__")
+        if D["nF"] > 0:
+            al = both("get", "getMaxAlphas_s__")
+            a0 = .99 * min(1.0, float(np.min(al)))
+            for trial in (a0, a0 * .99):
+                both("set", "setAlphaPrimal__", [trial])
+                both("get", "getMinF_s__")
+            if D["nG"] > 0:
+                both("set", "setAlphaDualEq__", [a0])
+            both("set", "setAlphaDualIneq__", [a0])
+        else:
+            both("set", "setAlphaPrimal__", [1.0])
+            if D["nG"] > 0:
+                both("set", "setAlphaDualEq__", [1.0])
+        both("copy", "updatePrimalDual__")
+        if D["nF"] > 0:
+            mu *= .2
+            both("set", "setMu__", [mu])
+    both("get", f"{c}_getOutputs")
+    return cs
+
+
+def test_ldsm_stream_sls(sls_spec, tape_oracle):
+    from tenscalc_amd.problems.sls import SOLVE_ARGS, sls_data
+    A, b, x0 = sls_data(3)
+    cs = _check(sls_spec, dict(A=A, b=b, x=x0), tape_oracle, SOLVE_ARGS)
+    kinds = set((np.asarray(cs["headers"]).reshape(-1, 8)[:, 0] >> 8).tolist())
+    assert {lsch.K_SHORT, lsch.K_FOLD} <= kinds            # the 300-operand sums are staged and folded
+
+
+@pytest.mark.parametrize("W", [1, 4])
+def test_ldsm_stream_dcmotor(native_built, tape_oracle, tmp_path, W):
+    """nG > 0 (second LDL for initDualEqX__), W = 4: records of every step spread over 4 waves + barriers"""
+    from tenscalc_amd.problems.mpc_dcmotor import SOLVE_ARGS, dcmotor_data, mpc_dcmotor
+    spec = mpc_dcmotor(folder=str(tmp_path))
+    _check(spec, dcmotor_data(7), tape_oracle, SOLVE_ARGS, W)
+
+
+def test_ldsm_stream_dcmotor_small_lds(native_built, tape_oracle, tmp_path):
+    """a tight LDS budget forces blocks into the per-instance HBM array: cold addresses, global flags"""
+    from tenscalc_amd.problems.mpc_dcmotor import SOLVE_ARGS, dcmotor_data, mpc_dcmotor
+    spec = mpc_dcmotor(folder=str(tmp_path))
+    cs = _check(spec, dcmotor_data(8), tape_oracle, SOLVE_ARGS, W=2, lds_slots=4600)
+    assert cs["nCold"] > 0 and cs["nLds"] <= 4600
+
+
+def test_ldsm_stream_small_quadcopter(native_built, tape_oracle, tmp_path):
+    """sqrt / Dsqrt / DDsqrt / inv-family opcodes and long dot products (T=8 horizon)"""
+    from tenscalc_amd.problems.mpc_quadcopter import SOLVE_ARGS, mpc_quadcopter, quadcopter_data
+    spec = mpc_quadcopter(T=8, classname="tmp_quadcopter8", folder=str(tmp_path))
+    _check(spec, quadcopter_data(1, T=8), tape_oracle, SOLVE_ARGS, W=4)
+
+
+def test_ldsm_validator_rejects_bad_addresses(sls_spec):
+    cs = lsch.class_stream(sls_spec.tape, sls_spec.classname, sls_spec.defines)
+    w = list(cs["words"])
+    hd = np.asarray(cs["headers"]).reshape(-1, 8)
+    w[int(hd[0, 4])] = cs["nLds"] + cs["nGlob"] + 5        # destination of the first record outside the state
+    with pytest.raises(AssertionError):
+        lsch.validate(w, cs["headers"], cs["table"], cs["W"], cs["nLds"], cs["nLds"] + cs["nGlob"])
