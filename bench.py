@@ -49,8 +49,8 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--batch", type=int, default=65536, help="instances per GPU")
-    ap.add_argument("--variant", default=os.environ.get("TC_BENCH_VARIANT", "w8x"), choices=["strict", "fast", "w8", "w8h", "regs", "regsl", "w8s", "w8x"],
+    ap.add_argument("--batch", type=int, default=0, help="instances per GPU (default: the config's)")
+    ap.add_argument("--variant", default=os.environ.get("TC_BENCH_VARIANT", ""),
                     help="w8x (default): 8 lanes/instance wave-cooperative lowering of the REFERENCE tape with the "
                          "reference's arithmetic kept bit for bit (parity class bit-exact: status, iteration count and "
                          "outputs identical to the cmex reference on every instance); strict: 1 thread/instance, "
@@ -60,7 +60,19 @@ def main():
                          "CU -- parity class solver-tolerance; w8h / regs / regsl: other lowerings of the hoisted tape")
     ap.add_argument("--cpu-sample", type=int, default=int(os.environ.get("TC_CPU_SAMPLE", "65536")))
     ap.add_argument("--no-cpu", action="store_true")
+    ap.add_argument("--config", default="sls", choices=["sls", "l1l2", "dcmotor", "quadcopter"],
+                    help="sls (default): BASELINE.json's metric, configs[1].  The others are BASELINE configs[2..4] in the "
+                         "same JSON vocabulary: l1l2 16384 instances, dcmotor 32768 (the whole 8-GPU sweep on one GPU), "
+                         "quadcopter 512 (configs[4]'s per-GPU share of 4096) per GPU; --batch overrides")
+    ap.add_argument("--gather-every-step", action="store_true",
+                    help="N>1: all-gather the results after EVERY step (overlapped with the next solve) instead of once "
+                         "after the K steps (SURVEY.md 8e: one gather at the end)")
     args = ap.parse_args()
+    if args.config != "sls":
+        return bench_config(args)
+    args.variant = args.variant or "w8x"
+    if args.variant not in ("strict", "fast", "w8", "w8h", "regs", "regsl", "w8s", "w8x"):
+        ap.error("--variant for --config sls: strict, fast, w8, w8h, regs, regsl, w8s or w8x")
 
     import numpy as np
     import torch
@@ -99,7 +111,7 @@ def main():
         bar()
     so = spec.build(**kw)
 
-    B = args.batch
+    B = args.batch or 65536
     A, b, x0 = make_batch(B, rank, dev)
     obj = HipSolver(so, B=B, device=local)
     stream = torch.cuda.current_stream().cuda_stream
@@ -134,9 +146,11 @@ def main():
                 pending[k].wait()
                 pending[k] = None
 
+    every = world > 1 and args.gather_every_step
+
     def step():
         obj.solve_async(SOLVE_ARGS["mu0"], SOLVE_ARGS["maxIter"], SOLVE_ARGS["addEye2Hessian"], stream=stream)
-        if world > 1:
+        if every:
             exchange()
 
     for _ in range(args.warmup):
@@ -154,10 +168,12 @@ def main():
         evs[k][0].record()
         obj.solve_async(SOLVE_ARGS["mu0"], SOLVE_ARGS["maxIter"], SOLVE_ARGS["addEye2Hessian"], stream=stream)
         evs[k][1].record()
-        if world > 1:
+        if every:
             exchange()
     if world > 1:
-        drain()                    # every gather of the K steps has completed inside the timed region
+        if not every:
+            exchange()             # the path's only exchange: ONE gather of the results, after the K steps
+        drain()                    # ... completed inside the timed region
     torch.cuda.synchronize()
     if world > 1:
         bar()
@@ -192,7 +208,8 @@ def main():
                                 "reference tape, tests/test_gpu_parity.py" if args.variant in g.HOISTED else "reference"),
                        "solved_fraction": solved_per_step / (B * world),
                        "iter_median": float(np.median(it)), "iter_max": int(it.max()),
-                       "sharding": "independent instances per rank, RCCL all_gather of results only (overlapped with the next solve)"},
+                       "sharding": "independent instances per rank; RCCL all_gather of the results only, "
+                                   + ("after every step, overlapped with the next solve" if every else "once after the K steps")},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBPS, "traffic": measured_traffic(args.variant, B),
                          "kernel": "tc_solve_kernel", "kernel_ms_avg": kavg * 1e3,
@@ -258,11 +275,51 @@ def measured_traffic(variant, B):
         return None
 
 
+def _cpu_worker(rank, n, q):
+    """one process of the all-cores CPU baseline: its own copy of the generated-C twin (the reference's generated C
+    keeps its state in globals: one instance stream per process, SURVEY.md 8b "Threading")"""
+    import numpy as np
+    import __graft_entry__ as g
+    from oracle.c_emitter import CpuTwin
+    from tenscalc_amd.problems.sls import SOLVE_ARGS
+    tw = CpuTwin(g.sls_spec("strict"))
+    rs = np.random.RandomState(100 + rank)
+    A = rs.random_sample((n, 800)); b = rs.random_sample((n, 100)); x0 = .02 * rs.random_sample((n, 8))
+    tw.solve_batch({"A": A[:64], "b": b[:64], "x": x0[:64]}, 64, mu0=SOLVE_ARGS["mu0"], maxIter=SOLVE_ARGS["maxIter"])
+    t0 = time.perf_counter()
+    out, st, it = tw.solve_batch({"A": A, "b": b, "x": x0}, n, mu0=SOLVE_ARGS["mu0"], maxIter=SOLVE_ARGS["maxIter"])
+    q.put((rank, time.perf_counter() - t0, int((st == 0).sum())))
+
+
+def cpu_all_cores(per_worker=30000):
+    """the same CPU path on every host core this process may use (one worker process per core, each solving its
+    own `per_worker` instances of the same distribution): aggregate solves/s, or None when the twin is not built"""
+    import multiprocessing as mp
+    P = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    P = max(1, min(P, int(os.environ.get("TC_CPU_WORKERS", "16"))))      # a one-GPU box's share of the host is 16 cores
+    try:
+        ctx = mp.get_context("spawn")
+        q = ctx.Queue()
+        ps = [ctx.Process(target=_cpu_worker, args=(r, per_worker, q)) for r in range(P)]
+        for p_ in ps:
+            p_.start()
+        res = [q.get(timeout=300) for _ in range(P)]
+        for p_ in ps:
+            p_.join()
+    except Exception:              # a worker without the prebuilt twin: no all-cores figure
+        return None
+    wall = max(r[1] for r in res)
+    return {"value_all_cores": sum(r[2] for r in res) / wall, "cores_all": P,
+            "sample_all_cores": "%d worker processes x %d instances of the same distribution, slowest worker %.2f s"
+                                % (P, per_worker, wall)}
+
+
 def cpu_baseline(spec, A, b, x0, sample, solve_args):
     """The CPU restatement of the reference path timed on ONE host core over the first `sample`
-    instances of the same workload (kind "port").  Preferred: the generated-C twin (oracle/c_emitter.py:
-    the tape as reference-style straight-line C + the reference's ipmPD_CSsolver.c, gcc -O1, prebuilt
-    in the development container); fallback: the tape interpreter oracle/tc_oracle.c."""
+    instances of the same workload (kind "port"), and on all host cores this process may use (one worker process
+    per core).  Preferred: the generated-C twin (oracle/c_emitter.py: the tape as reference-style straight-line C +
+    the reference's ipmPD_CSsolver.c, gcc -O1, prebuilt in the development container); fallback: the tape
+    interpreter oracle/tc_oracle.c."""
     import numpy as np
     import __graft_entry__ as g
     c = spec.classname
@@ -270,6 +327,7 @@ def cpu_baseline(spec, A, b, x0, sample, solve_args):
     Ah = np.ascontiguousarray(A[:, :n].t().cpu().numpy())
     bh = np.ascontiguousarray(b[:, :n].t().cpu().numpy())
     xh = np.ascontiguousarray(x0[:, :n].t().cpu().numpy())
+    allc = None
     try:
         from oracle.c_emitter import CpuTwin
         tw = CpuTwin(spec)
@@ -282,6 +340,7 @@ def cpu_baseline(spec, A, b, x0, sample, solve_args):
         dt = (time.perf_counter() - t0) / reps
         what = ("generated-C twin of the tape (oracle/c_emitter.py) + reference lib/ipmPD_CSsolver.c, gcc -O1, "
                 "prebuilt oracle/_ref/lib%s_cpu.so" % c)
+        allc = cpu_all_cores()
     except (FileNotFoundError, OSError):
         from oracle.tc_oracle import Oracle
         o = Oracle(os.path.join(g.GENERATED, "@" + c, c + ".tape"))
@@ -291,10 +350,166 @@ def cpu_baseline(spec, A, b, x0, sample, solve_args):
         out, st, it = o.solve_batch(sets(n), c + "_getOutputs", n, mu0=solve_args["mu0"], maxIter=solve_args["maxIter"])
         dt = time.perf_counter() - t0
         what = "oracle/tc_oracle.c (tape interpreter + restated ipmPD_CSsolver loop, gcc -O1)"
-    return {"value": float((st == 0).sum()) / dt, "unit": "solves/s", "cores": 1, "kind": "port",
+    res = {"value": float((st == 0).sum()) / dt, "unit": "solves/s", "cores": 1, "kind": "port",
+           "sample": "first %d instances of the benchmark batch, %s, sequential on 1 of %d host cores, %.2f s per pass"
+                     % (n, what, os.cpu_count(), dt),
+           "us_per_solve": dt / n * 1e6}
+    if allc:
+        res.update(allc)
+    return res
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# BASELINE configs[2..4]: the same JSON vocabulary for the three large problems
+CONFIGS = {
+    # name: (module, builder, data fn, instances per GPU, default variant, CPU sample, workload label)
+    "l1l2": ("tenscalc_amd.problems.l1l2", "l1l2", "l1l2_data", 16384, "interp8", 2048,
+             "l1l2estimationCS N=200 (1792x1792 KKT, 54 k instructions), batch=%d per GPU, fp64 (BASELINE.json configs[2])"),
+    "dcmotor": ("tenscalc_amd.problems.mpc_dcmotor", "mpc_dcmotor", "dcmotor_data", 32768, "strict", 32768,
+                "mpc_dcmotor T=30 (323x323 KKT), batch=%d parameter sweep per GPU, fp64 (BASELINE.json configs[3]: the "
+                "whole 8-GPU sweep of 32768 on one GPU by default)"),
+    "quadcopter": ("tenscalc_amd.problems.mpc_quadcopter", "mpc_quadcopter", "quadcopter_data", 512, "ldsm4", 512,
+                   "mpc_quadcopter T=100 (1406x1406 KKT, 67 k instructions), batch=%d per GPU, fp64 (BASELINE.json "
+                   "configs[4]: the per-GPU share of 4096 over 8 GPUs)"),
+}
+
+
+def bench_config(args):
+    """python bench.py --config l1l2|dcmotor|quadcopter [--variant V] [--batch B]: one step = one batched solve of B
+    instances per GPU with the inputs resident in HBM; same timing contract and JSON fields as the sls line."""
+    import importlib
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+    import __graft_entry__ as g
+    from tenscalc_amd.runtime import HipSolver
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    torch.cuda.set_device(local)
+    dev = torch.device("cuda", local)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group(backend="nccl", device_id=dev)
+    modname, mk, datafn, B0, var0, ncpu, label = CONFIGS[args.config]
+    mod = importlib.import_module(modname)
+    SOLVE = mod.SOLVE_ARGS
+    variant = args.variant or var0                       # any key of __graft_entry__.VARIANT_KW (interp8, ldsm4, strict, ...)
+    B = args.batch or B0
+    spec = getattr(mod, mk)(folder=g.GENERATED)
+    kw = dict(g.VARIANT_KW[variant])
+    if rank == 0:
+        spec.build(**kw)
+    if world > 1:
+        dist.barrier(device_ids=[local])
+    so = spec.build(**kw)
+    names = [n for n, _ in spec.parameters + spec.variables]
+    nd = min(B, 256)                                           # 256 distinct seeded instances, tiled over the batch
+    ds = [getattr(mod, datafn)(rank * 256 + k) for k in range(nd)]
+    stacked = {n: np.stack([np.asarray(ds[k % nd][n], dtype=float).reshape(-1, order="F") for k in range(B)]) for n in names}
+    obj = HipSolver(so, B=B, device=local)
+    for n in names:
+        obj.set(n, stacked[n])
+    stream = torch.cuda.current_stream().cuda_stream
+    ae = SOLVE.get("addEye2Hessian", (1e-9, 1e-9))
+    for _ in range(args.warmup):
+        obj.solve_async(SOLVE["mu0"], SOLVE["maxIter"], ae, stream=stream)
+    evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
+    if world > 1:
+        dist.barrier(device_ids=[local])
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for k in range(args.steps):
+        evs[k][0].record()
+        obj.solve_async(SOLVE["mu0"], SOLVE["maxIter"], ae, stream=stream)
+        evs[k][1].record()
+    optr, sptr, iptr = obj.device_views()
+    nout = sum(o["numel"] for o in obj.outputs)
+    ST = torch.as_tensor(_DevArray(sptr, (B,), "<i4"), device=dev)
+    IT = torch.as_tensor(_DevArray(iptr, (B,), "<i4"), device=dev)
+    if world > 1:      # the path's only exchange: one gather of status / iteration counts / outputs after the K steps
+        O = torch.as_tensor(_DevArray(optr, (nout, B), "<f8"), device=dev)
+        from tenscalc_amd.sharding import pack_results
+        packed = pack_results(O, ST, IT)
+        gathered = torch.empty((world,) + tuple(packed.shape), dtype=packed.dtype, device=dev)
+        dist.all_gather_into_tensor(gathered.view(world * packed.shape[0], B), packed)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier(device_ids=[local])
+        torch.cuda.synchronize()
+    elapsed = time.perf_counter() - t0
+    el = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+    ok = (ST == 0).sum().to(torch.float64).reshape(1)
+    if world > 1:
+        dist.all_reduce(el, op=dist.ReduceOp.MAX)
+        dist.all_reduce(ok, op=dist.ReduceOp.SUM)
+    elapsed = float(el.item())
+    if rank == 0:
+        it = IT.cpu().numpy()
+        st = ST.cpu().numpy()
+        kavg = float(np.mean([a.elapsed_time(b_) for a, b_ in evs])) * 1e-3
+        nin = sum(int(np.prod(s_)) if len(s_) else 1 for _, s_ in spec.parameters + spec.variables)
+        algo = 8 * (nin + nout) + 8                               # SURVEY.md 8d: inputs + outputs + (status, iter)
+        achieved = algo * B / kavg / 1e9
+        out = {"metric": "IPM solves/sec (whole node), %s batch" % args.config, "value": float(ok.item()) * args.steps / elapsed,
+               "unit": "solves/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+               "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+               "dtype": "f64", "data": "synthetic",
+               "config": {"workload": label % B, "batch_per_gpu": B, "mu0": SOLVE["mu0"], "maxIter": SOLVE["maxIter"],
+                          "variant": variant, "parity_class": ("bit-exact" if args.config != "quadcopter" else
+                                                                "bit-exact between the device back-ends; vs the cmex reference "
+                                                                "1-iteration agreement 3e-10 (libm pow differs by 1 ulp), "
+                                                                "tests/test_gpu_interp.py"),
+                          "solved_fraction": float(ok.item()) / (B * world), "iter_median": float(np.median(it)),
+                          "iter_max": int(it.max()),
+                          "sharding": "independent instances per rank; one RCCL all_gather of the results after the K steps"},
+               "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                            "frac": achieved / HBM_PEAK_GBPS, "traffic": measured_traffic(args.config + "_" + variant, B),
+                            "kernel": "tc_solve_kernel", "kernel_ms_avg": kavg * 1e3,
+                            "algorithmic_bytes_per_launch": algo * B, "algorithmic_bytes_per_solve": algo}}
+        if not args.no_cpu and world == 1:
+            out["cpu_baseline"] = cpu_baseline_config(spec, args.config, stacked, names, min(B, ncpu), SOLVE, st, it)
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier(device_ids=[local])
+        dist.destroy_process_group()
+    obj.close()
+
+
+def cpu_baseline_config(spec, which, stacked, names, n, SOLVE, st, it):
+    """bounded sample of the same workload on one host core: the generated-C twin where it is prebuilt (dcmotor),
+    else the oracle's tape interpreter (the twins of the big tapes are 44 MB C files gcc needs an hour for)"""
+    import numpy as np
+    sub = {k: v[:n] for k, v in stacked.items()}
+    twin = None
+    if which == "dcmotor":
+        try:
+            from oracle.c_emitter import CpuTwin
+            twin = CpuTwin(spec)
+        except (FileNotFoundError, OSError):
+            twin = None
+    if twin is not None:
+        run = lambda: twin.solve_batch(sub, n, mu0=SOLVE["mu0"], maxIter=SOLVE["maxIter"])      # noqa: E731
+        how = "generated-C twin + reference ipmPD_CSsolver.c, gcc -O1"
+    else:
+        from tenscalc_amd.tapeio import save_tape
+        from oracle.tc_oracle import Oracle
+        save_tape(spec.tape, "/tmp/%s.tape" % which)
+        c = spec.classname
+        o = Oracle("/tmp/%s.tape" % which)
+        run = lambda: o.solve_batch({f"{c}_set_{k}": v for k, v in sub.items()}, c + "_getOutputs", n,      # noqa: E731
+                                    mu0=SOLVE["mu0"], maxIter=SOLVE["maxIter"])
+        how = "oracle tape interpreter (oracle/tc_oracle.c: same arithmetic as the generated C, about 2-5x slower)"
+    t0 = time.perf_counter()
+    reps = 0
+    while reps == 0 or (time.perf_counter() - t0 < 8.0 and reps < 64):        # ~10 s of CPU work
+        out, st2, it2 = run()
+        reps += 1
+    dt = (time.perf_counter() - t0) / reps
+    return {"value": float((st2 == 0).sum()) / dt, "unit": "solves/s", "cores": 1, "kind": "port",
             "sample": "first %d instances of the benchmark batch, %s, sequential on 1 of %d host cores, %.2f s per pass"
-                      % (n, what, os.cpu_count(), dt),
-            "us_per_solve": dt / n * 1e6}
+                      % (n, how, os.cpu_count(), dt),
+            "same_status_iter": bool(np.array_equal(st[:n], st2) and np.array_equal(it[:n], it2))}
 
 
 if __name__ == "__main__":
