@@ -1,0 +1,108 @@
+"""Tape construction of mpc_dcmotor and l1l2 pinned WITHOUT going through tcalculus.py / csparse.py: the scalar tape
+(front-end port + scalarizers + symbolic LDL in OUR elimination order), evaluated by the oracle, must walk the same
+iterates as a dense numpy interior-point method whose matrices are written down by hand from the problem statements
+(tests/dense_ipm.py), and end at the optimum an independent solver (scipy SLSQP) finds.
+
+Tolerances.  The two codes round differently (dense LU vs sparse LDL', different summation orders), and the KKT
+systems carry 1e-9 regularisation, so iterates agree to ~1e-9 relative over the first Newton steps (asserted: 1e-7)
+and the complete solves agree to the solver's own tolerance; status and iteration counts must be equal."""
+import numpy as np
+import pytest
+
+from dense_ipm import dcmotor_qp, l1l2_qp, solve_qp_dense
+
+
+def _oracle_runs(spec, tape_oracle, data, args, iters):
+    T, c = spec.tape, spec.classname
+    o = tape_oracle(T, c)
+    names = [n for n, _ in spec.parameters + spec.variables]
+    res = {}
+    for mi in iters:
+        for n in names:
+            o.set(f"{c}_set_{n}", data[n])
+        st, it = o.solve(args["mu0"], mi, -1, args["addEye2Hessian"])
+        res[mi] = (st, it, o.get(c + "_getOutputs"))
+    return res
+
+
+def _outputs_slices(spec):
+    off, sl = 0, {}
+    for nm, sz in spec.outputs:
+        k = int(np.prod(sz)) if len(sz) else 1
+        sl[nm] = slice(off, off + k)
+        off += k
+    return sl
+
+
+@pytest.mark.parametrize("seed", [7, 8, 9])
+def test_dcmotor_tape_vs_dense_ipm(native_built, tape_oracle, tmp_path, seed):
+    from tenscalc_amd.problems.mpc_dcmotor import SOLVE_ARGS, dcmotor_data, mpc_dcmotor
+    spec = mpc_dcmotor(folder=str(tmp_path))
+    d = dcmotor_data(seed)
+    P, q, r, E, e, C, dd, u0 = dcmotor_qp(d)
+    assert (len(q), E.shape[0], C.shape[0]) == (spec.defines["nU"], spec.defines["nG"], spec.defines["nF"])
+    sl = _outputs_slices(spec)
+    runs = _oracle_runs(spec, tape_oracle, d, SOLVE_ARGS, [1, 2, 3, SOLVE_ARGS["maxIter"]])
+    for mi, (st, it, y) in runs.items():
+        dst, dit, u, _, _ = solve_qp_dense(P, q, r, E, e, C, dd, u0, SOLVE_ARGS["mu0"], mi)
+        assert (st & 15, it) == (dst, dit), (mi, st, it, dst, dit)       # the low bits: 0 converged, 8 maxIter
+        got = np.r_[y[sl["u"]], y[sl["x"]]]                              # packed [u, x(:)] like the dense code
+        tol = 1e-7 if mi <= 3 else 1e-5
+        assert np.abs(got - u).max() <= tol * (1 + np.abs(u).max()), (mi, np.abs(got - u).max())
+        J = .5 * u @ (P @ u) + q @ u + r
+        assert abs(y[sl["J"]][0] - J) <= 1e-6 * (1 + abs(J))
+    # the optimum itself, from an independent solver
+    from scipy.optimize import minimize
+    st, it, y = runs[SOLVE_ARGS["maxIter"]]
+    assert st == 0
+    ref = minimize(lambda v: .5 * v @ (P @ v) + q @ v + r, u0, jac=lambda v: P @ v + q, method="SLSQP",
+                   constraints=[dict(type="eq", fun=lambda v: E @ v + e, jac=lambda v: E),
+                                dict(type="ineq", fun=lambda v: C @ v + dd, jac=lambda v: C)],
+                   options=dict(maxiter=500, ftol=1e-12))
+    assert ref.success
+    assert abs(y[sl["J"]][0] - ref.fun) <= 1e-4 * (1 + abs(ref.fun))       # duality gap 1e-5, gradTolerance 1e-4
+    assert np.abs(np.r_[y[sl["u"]], y[sl["x"]]] - ref.x).max() <= 5e-3
+
+
+def test_l1l2_tape_vs_dense_ipm(native_built, tape_oracle, tmp_path):
+    """full size (N=200, 1792x1792 KKT, scaleCost): first Newton steps and the complete solve against the dense code"""
+    from tenscalc_amd.problems.l1l2 import SOLVE_ARGS, l1l2, l1l2_data
+    spec = l1l2(folder=str(tmp_path))
+    d = l1l2_data(11)
+    P, q, r, E, e, C, dd, u0 = l1l2_qp(d)
+    assert (len(q), C.shape[0]) == (spec.defines["nU"], spec.defines["nF"])
+    runs = _oracle_runs(spec, tape_oracle, d, SOLVE_ARGS, [1, 2, SOLVE_ARGS["maxIter"]])
+    for mi, (st, it, y) in runs.items():
+        dst, dit, u, _, _ = solve_qp_dense(P, q, r, E, e, C, dd, u0, SOLVE_ARGS["mu0"], mi, scaleCost=1.0, gapTol=1e-3)
+        assert (st & 15, it) == (dst, dit), (mi, st, it, dst, dit)
+        got = y[1:]
+        tol = 1e-7 if mi <= 2 else 1e-4
+        assert np.abs(got - u).max() <= tol * (1 + np.abs(u).max()), (mi, np.abs(got - u).max())
+        J = .5 * u @ (P @ u) + q @ u + r
+        assert abs(y[0] - J) <= 1e-6 * (1 + abs(J))
+
+
+def test_l1l2_small_vs_scipy(native_built, tape_oracle, tmp_path):
+    """the same problem statement at N=24 (212 unknowns): the tape's optimum against scipy SLSQP"""
+    from scipy.optimize import minimize
+    from tenscalc_amd.problems.l1l2 import SOLVE_ARGS, l1l2, l1l2_data
+    N = 24
+    spec = l1l2(N=N, classname="tmp_l1l2_small", folder=str(tmp_path))
+    d = l1l2_data(3, N=N)
+    P, q, r, E, e, C, dd, u0 = l1l2_qp(d, N=N)
+    st, it, y = _oracle_runs(spec, tape_oracle, d, SOLVE_ARGS, [SOLVE_ARGS["maxIter"]])[SOLVE_ARGS["maxIter"]]
+    assert st == 0
+    ref = minimize(lambda v: .5 * v @ (P @ v) + q @ v + r, u0, jac=lambda v: P @ v + q, method="SLSQP",
+                   constraints=[dict(type="ineq", fun=lambda v: C @ v + dd, jac=lambda v: C)],
+                   options=dict(maxiter=2000, ftol=1e-10))
+    # SLSQP may stop with "positive directional derivative for linesearch" (status 8) AT the optimum of this
+    # piecewise-linear-plus-quadratic problem: accept it only with a vanishing projected gradient
+    assert ref.success or ref.status == 8
+    act = (C @ ref.x + dd) < 1e-7
+    g = P @ ref.x + q
+    Z = C[act]
+    lam_ls = np.linalg.lstsq(Z.T, g, rcond=None)[0] if act.any() else np.zeros(0)
+    assert np.abs(g - (Z.T @ lam_ls if act.any() else 0)).max() <= 1e-4 and (lam_ls >= -1e-6).all()     # KKT at ref.x
+    print("\nl1l2 N=24: tape optimum J=%.9g, scipy SLSQP J=%.9g (status %d)" % (y[0], ref.fun, ref.status))
+    assert abs(y[0] - ref.fun) <= 2e-3 * (1 + abs(ref.fun))               # desiredDualityGap 1e-3 (scaled cost)
+    assert y[0] >= ref.fun - 1e-6 * (1 + abs(ref.fun))                    # an interior point: never below the optimum
