@@ -12,7 +12,9 @@ def main(out, rnd, var):
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     dst = os.path.join(root, "gpurun_out", "profiles_%s" % rnd)
     os.makedirs(dst, exist_ok=True)
-    lines = ["rocprofv3 --kernel-trace --stats summary of: python3 bench.py --steps 20 --warmup 3 --no-cpu --variant %s" % var,
+    cmdline = ("--steps 20 --warmup 3 --no-cpu --variant %s" % var) if "_" not in var else \
+        ("--config %s --variant %s --steps 3 --warmup 1 --no-cpu" % tuple(var.split("_", 1)))
+    lines = ["rocprofv3 --kernel-trace --stats summary of: python3 bench.py " + cmdline,
              "Name,Calls,TotalDurationNs,AverageNs,Percentage,MinNs,MaxNs,StdDev"]
     kavg = None
     for f in glob.glob(os.path.join(out, "kt", "*", "*_kernel_stats.csv")):
@@ -51,7 +53,8 @@ def main(out, rnd, var):
     tj = os.path.join(dst, "traffic.json")
     t = json.load(open(tj)) if os.path.exists(tj) else {}
     if traffic is not None:
-        t["%s_B65536" % var] = {"hbm_bytes_per_launch": traffic, "fetch_size_kib": pm["FETCH_SIZE"],
+        B = {"quadcopter": 512, "l1l2": 16384, "dcmotor": 32768}.get(var.split("_")[0], 65536)
+        t["%s_B%d" % (var, B)] = {"hbm_bytes_per_launch": traffic, "fetch_size_kib": pm["FETCH_SIZE"],
                                 "write_size_kib": pm["WRITE_SIZE"], "kernel_avg_ns": kavg, "round": rnd}
     json.dump(t, open(tj, "w"), indent=1)
     print("\n".join(lines[-14:]))
