@@ -413,6 +413,37 @@ static void run_instruction(tco_t *t, int64_t i) {
     case 46: *r = 1 / (2 + exp(-M(0)) + exp(M(0))); break;
     case 47: *r = (M(0) > 0) ? M(0) : 0; break;
     case 48: *r = (M(0) > 0) ? 1 : 0; break;
+    case 49: *r = 0; break; /* I_zero */
+    case 50: { /* I_componentwise :1333-1345: C text in the parameters, 0 = the operand.  An interpreter cannot run
+                  arbitrary C: the plain calls NAME(operand) of the functions below are evaluated, anything else aborts */
+      char nm[32];
+      int64_t np_ = t->parStart[i] - t->parStart[i - 1], q = 0, hole = -1;
+      size_t ln = 0;
+      for (q = 0; q < np_; q++) {
+        int ch = (int)par[q];
+        if (ch == 0) { hole = q; continue; }
+        if (ch == ' ' || ch == '(' || ch == ')') continue;
+        if (hole >= 0 || ln + 1 >= sizeof nm) { ln = 0; break; }
+        nm[ln++] = (char)ch;
+      }
+      nm[ln] = 0;
+      x = M(0);
+      if (!strcmp(nm, "fabs") || !strcmp(nm, "abs")) *r = fabs(x);
+      else if (!strcmp(nm, "sqrt")) *r = sqrt(x);
+      else if (!strcmp(nm, "exp")) *r = exp(x);
+      else if (!strcmp(nm, "log")) *r = log(x);
+      else if (!strcmp(nm, "sin")) *r = sin(x);
+      else if (!strcmp(nm, "cos")) *r = cos(x);
+      else if (!strcmp(nm, "atan")) *r = atan(x);
+      else if (!strcmp(nm, "round")) *r = round(x);
+      else if (!strcmp(nm, "ceil")) *r = ceil(x);
+      else if (!strcmp(nm, "floor")) *r = floor(x);
+      else {
+        fprintf(stderr, "tc_oracle: I_componentwise text not understood (only NAME(operand) calls)\n");
+        abort();
+      }
+      break;
+    }
     default:
       fprintf(stderr, "tc_oracle: unsupported opcode %lld\n", (long long)t->types[i - 1]);
       abort();

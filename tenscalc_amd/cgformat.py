@@ -76,7 +76,8 @@ def save_cg(T, basename, word=64, extensions=True):
 
     word=32, extensions=False reproduces what the reference's saveScalarized writes (int32 index words, no
     descriptions, no defines) -- such a file loads only with load_cg(..., defines=...) and cannot carry opcodes
-    the registry has no name for."""
+    the registry has no name for; extensions="opcodes": the same, but unregistered opcodes are written with their
+    extension type ids (a reference file of a tape the reference's writer would refuse)."""
     consts = []                       # (type, payload)
     nvar = [T.n]
     fg, fio, fs = (_Writer(basename + e, word) for e in (".cg", ".cgio", ".cgs"))
@@ -111,7 +112,7 @@ def save_cg(T, basename, word=64, extensions=True):
     nio = [0]
 
     def sym(name, desc=""):
-        if not extensions:
+        if extensions is not True:
             desc = ""
         fs.w(SYM_IO, nio[0], len(name), len(desc))
         fs.raw(name.encode() + desc.encode())
@@ -142,7 +143,7 @@ def save_cg(T, basename, word=64, extensions=True):
     for e in T.copies:                                          # :248-277
         fio.w(IO_COPY, len(e["src"]), *[i - 1 for i in e["src"]], *[i - 1 for i in e["dst"]])
         sym(e["name"])
-    if extensions:
+    if extensions is True:
         for k, v in sorted(T.defines.items()):
             d = repr(float(v))
             fs.w(SYM_DEFINE, 0, len(k), len(d))

@@ -545,6 +545,19 @@ class CSparse:
             return _empty(len(n.size))
         return subs, self.table.append_many(I.COMPOSE_OPCODE[fun], None, ins[:, None])
 
+    def _s_componentwise(self, n):
+        """sparsity_componentwise.m:35: one I_componentwise per entry (structurally full result); the parameters are
+        the characters of the C text with 0 in place of the operand hole (instructionsTableUTHash.c:1333-1345)"""
+        subs, ins = self._arg(n)
+        tot = tc._prod(n.size)
+        allins = np.zeros(tot, dtype=np.int64)
+        allins[_lin(subs, n.size)] = ins
+        if (allins == 0).any():
+            allins[allins == 0] = self.load(0.0)
+        a, b = n.par.split("%s")
+        par = [float(ord(ch)) for ch in a] + [0.0] + [float(ord(ch)) for ch in b]
+        return _full_subs(n.size), self.table.append_many(I.I_componentwise, np.tile(par, (tot, 1)), allins[:, None])
+
     def _minmax(self, n, t_full, t_zero):
         subs, ins = self._arg(n)
         x = n.args[0]

@@ -726,6 +726,10 @@ class Printer:
                     e = st_.replace("a_", e, 1)
                 return e
             return "({ double a_ = " + init + "; " + " ".join(f"a_ = {st_};" for st_ in steps) + " a_; })"
+        if typ == I.I_zero:
+            return "0.0"
+        if typ == I.I_componentwise:      # the reference prints the C text verbatim with m[operand] in the hole (:1333-1345)
+            return "(" + I.componentwise_text(par).replace("%s", "(" + r[0] + ")") + ")"
         if typ in _UNARY:
             return _UNARY[typ].format(r[0] if r else "")
         raise NotImplementedError(f"HIP emitter: opcode {I.NAMES.get(typ, typ)} not supported")

@@ -83,6 +83,24 @@ COMPOSE_KEEPS_ZERO = {
     "3sqr", "6times", "atan", "DDatan", "relu", "heaviside",
 }
 
+# I_componentwise: the data-driven evaluators (oracle, interp, ldsm) cannot run arbitrary C text; they accept the
+# strings that are a plain call of one of these functions on the operand and run the matching opcode instead
+COMPONENTWISE_CALLS = {"fabs": I_abs, "abs": I_abs, "sqrt": I_sqrt, "exp": I_exp, "log": I_log, "sin": I_sin,
+                       "cos": I_cos, "atan": I_atan, "round": I_round, "ceil": I_ceil, "floor": I_floor}
+
+
+def componentwise_text(par):
+    """parameters of an I_componentwise instruction -> (C text with %s for the operand hole)"""
+    return "".join("%s" if int(p) == 0 else chr(int(p)) for p in par)
+
+
+def componentwise_opcode(par):
+    """opcode equivalent to the C text, or None"""
+    import re
+    m = re.fullmatch(r"\s*([A-Za-z_][A-Za-z0-9_]*)\s*\(\s*%s\s*\)\s*", componentwise_text(par))
+    return COMPONENTWISE_CALLS.get(m.group(1)) if m else None
+
+
 # flop-count classes (instructionsTableTypes.h:108-126)
 P_nsum, P_nprod, P_ndiv, P_nif, P_nclp, P_nabs, P_nround, P_nceil, P_nfloor, P_nsign, \
     P_nsqrt, P_npow, P_ntrig, P_nlog, P_nexp, P_cpwise, P_numfpack = range(17)

@@ -129,7 +129,14 @@ def build_stream(T, row_of, W=1):
                     if aux * int(par[1]) != len(ops):
                         raise AssertionError("I_sumprod operand count")
                     a = [row_of(j) * 2 for j in ops]
-                elif op >= I.I_componentwise or op in (I.I_set, I.I_load):
+                elif op == I.I_componentwise:
+                    eq = I.componentwise_opcode(par)
+                    if eq is None:
+                        raise NotImplementedError("table-driven back-ends run I_componentwise only for plain calls of "
+                                                  + str(sorted(I.COMPONENTWISE_CALLS)) + "; got " + repr(I.componentwise_text(par)))
+                    op = eq
+                    a = [int(row_of(j)) * 2 for j in ops]
+                elif op > I.I_componentwise or op in (I.I_set, I.I_load):
                     raise NotImplementedError(f"table-driven back-end: opcode {I.NAMES.get(op, op)}")
                 else:
                     a = [row_of(j) * 2 for j in ops]

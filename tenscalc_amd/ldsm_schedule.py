@@ -288,7 +288,14 @@ def build_stream(T, addr, nLds, W=1, stage_base=None, nStage=0):
                 elif op == I.I_sumprod:
                     aux = int(par[0])
                     a = [int(addr[j]) * 2 for j in ops]
-                elif op >= I.I_componentwise or op in (I.I_set, I.I_load):
+                elif op == I.I_componentwise:
+                    eq = I.componentwise_opcode(par)
+                    if eq is None:
+                        raise NotImplementedError("table-driven back-ends run I_componentwise only for plain calls of "
+                                                  + str(sorted(I.COMPONENTWISE_CALLS)) + "; got " + repr(I.componentwise_text(par)))
+                    op = eq
+                    a = [int(addr[j]) * 2 for j in ops]
+                elif op > I.I_componentwise or op in (I.I_set, I.I_load):
                     raise NotImplementedError(f"ldsm back-end: opcode {I.NAMES.get(op, op)}")
                 else:
                     a = [int(addr[j]) * 2 for j in ops]

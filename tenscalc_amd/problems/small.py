@@ -24,3 +24,32 @@ def small_ls(kind, N=12, n=4, **options):
     return cmex2optimizeCS(classname="tmp_small_" + kind, objective=J, optimizationVariables=[x],
                            constraints=cons, outputExpressions=[J, x], outputNames=["J", "x"],
                            parameters=[A, b], **opt)
+
+
+# every unary opcode of the scalar ISA that the BASELINE problems do not reach, as OUTPUT expressions of a small
+# box-constrained least-squares problem (evaluated once, by getOutputs): transcendental families, rounding, the
+# derivative chains of sqrt / atan / srelu, I_componentwise (C text) -- tests/test_gpu_opcodes.py
+OPCODE_FUNS = ["exp", "log", "sin", "minus_sin", "cos", "minus_cos", "round", "ceil", "floor", "abs", "sign", "sqrt",
+               "Dsqrt", "DDsqrt", "sqr", "2times", "cube", "3sqr", "6times", "atan", "Datan", "DDatan", "srelu", "dsrelu",
+               "ddsrelu", "relu", "heaviside", "inv", "minus_inv_sqr", "2_inv_cube"]
+
+
+def opcode_zoo(N=12, n=4, classname="tmp_opcode_zoo", **options):
+    A = tc.Tvariable("A", (N, n))
+    b = tc.Tvariable("b", (N,))
+    x = tc.Tvariable("x", (n,))
+    J = tc.norm2(A * x - b) / N
+    z = 40.0 * x - 1.0 + b[0:n]                 # spread arguments: roughly (-1, 2)
+    pos = 40.0 * x + .25                         # positive arguments for log / sqrt / inverse families
+    outs, names = [J, x], ["J", "x"]
+    for f in OPCODE_FUNS:
+        arg = pos if f in ("log", "sqrt", "Dsqrt", "DDsqrt", "inv", "minus_inv_sqr", "2_inv_cube") else z
+        outs.append(tc.compose(arg, f))
+        names.append("f_" + f.replace("2", "two").replace("3", "three").replace("6", "six"))
+    outs.append(tc.componentwise(z, "fabs(%s)"))
+    names.append("cw_fabs")
+    outs.append(tc.componentwise(pos, "sqrt( %s )"))
+    names.append("cw_sqrt")
+    return cmex2optimizeCS(classname=classname, objective=J, optimizationVariables=[x],
+                           constraints=[x >= 0, x <= .05], outputExpressions=outs, outputNames=names,
+                           parameters=[A, b], **options)

@@ -16,12 +16,14 @@ product for two 1-D operands), ``times(a,b)`` is element-wise, ``/`` is ``rdivid
 """
 from __future__ import annotations
 
+import re
+
 import numpy as np
 
 __all__ = [
     "Tcalculus", "Tvariable", "Tconstant", "Tzeros", "Tones", "Teye", "clear",
     "plus", "tprod", "mtimes", "times", "rdivide", "norm2", "norminf", "norm1",
-    "compose", "tabs", "sqr", "sqrt", "cube", "exp", "log", "sin", "cos", "inv_",
+    "compose", "componentwise", "tabs", "sqr", "sqrt", "cube", "exp", "log", "sin", "cos", "inv_",
     "heaviside", "relu", "tmin", "tmax", "min2", "max2", "clp", "cat", "subsref",
     "reshape", "repmat", "diag", "transpose", "ldl", "ldl_d", "ldl_l", "mldivide",
     "full", "tsum", "gradient", "hessian", "substitute", "toT", "expand",
@@ -465,6 +467,19 @@ def compose(x, fun):
     return Tcalculus.make("compose", x.size, (x,), fun)
 
 
+def componentwise(x, cfun):
+    """Element-wise application of a scalar function given as C text with one ``%s`` hole for the operand, e.g.
+    ``componentwise(x, "fabs(%s)")``: the reference's ``componentwise(obj,fun,cfun,...)`` (@Tcalculus/Tcalculus.m:
+    2029-2031 uses it for abs), scalarized to I_componentwise (@csparse/sparsity_componentwise.m:35,
+    instructionsTableUTHash.c:1333).  The result is structurally full; no derivative is defined."""
+    x = toT(x)
+    if cfun.count("%s") != 1:
+        raise ValueError("componentwise: the C text needs exactly one %s hole")
+    if not re.fullmatch(r"[A-Za-z0-9_+\-*/().,<>=?:%& |!]+", cfun):
+        raise ValueError("componentwise: unsupported character in C text %r" % cfun)
+    return Tcalculus.make("componentwise", x.size, (x,), cfun)
+
+
 def tabs(x):
     return compose(x, "abs")
 
@@ -825,6 +840,8 @@ def _gradient(f, var):
         x = f.args[0]
         neg = tuple(-k for k in range(1, x.ndim + 1))
         return tprod(Tconstant(2.0), (), gs[0], neg + vix, x, neg)
+    if op == "componentwise":
+        raise NotImplementedError("componentwise(%r) has no derivative" % f.par)
     if op == "compose":
         d = _FUNS[f.par][0]
         if d is None:
@@ -971,6 +988,8 @@ def _rebuild(f, a):
         return norm1(a[0])
     if op == "compose":
         return compose(a[0], f.par)
+    if op == "componentwise":
+        return componentwise(a[0], f.par)
     if op in ("min", "max"):
         return _reduce(op, a[0], f.par)
     if op == "min2":

@@ -80,6 +80,22 @@ def spec_from_tape(path, folder=None):
     return spec
 
 
+def spec_from_cg(basename, defines=None, folder=None):
+    """SolverSpec from computation-graph files <basename>.{cg,cgc,cgio,cgs} -- as our save_cg writes them or as the
+    reference's saveScalarized does (cgformat.load_cg; a reference-written file carries no solver #define block:
+    pass the dict of cmex2optimizeCS.m:303-331)."""
+    from ..cgformat import load_cg
+    T = load_cg(basename, defines=defines)
+    get = [e for e in T.gets if e["name"].endswith("_getOutputs")]
+    if len(get) != 1:
+        raise ValueError("computation graph has no unique <cls>_getOutputs gateway")
+    cls = get[0]["name"][:-len("_getOutputs")]
+    ext = [e for e in T.sets if e["external"]]
+    return SolverSpec(cls, T, T.defines, [(e["varname"], e["size"]) for e in ext], [],
+                      [(o["name"], o["size"]) for o in get[0]["outputs"]],
+                      folder or os.path.dirname(os.path.abspath(basename)))
+
+
 def main(argv=None):
     ap = argparse.ArgumentParser(description=__doc__)
     ap.add_argument("tape")

@@ -1,0 +1,88 @@
+"""GPU: the unary opcodes of the scalar ISA that the BASELINE problems do not reach (transcendental families,
+rounding, derivative chains of sqrt / atan / srelu, I_componentwise) through every back-end, and a class built from
+REFERENCE-dialect computation-graph files.
+
+Tolerances, written here: opcodes made of IEEE + - * / sqrt fabs and comparisons are BIT-IDENTICAL to the oracle.
+exp / log / sin / cos / atan / pow come from the device math library vs glibc on the host: both are accurate to
+about 1 ulp but not correctly rounded, so outputs built on them must agree within 4 ulp (measured and printed;
+scripts/powcheck quantifies pow: 1 ulp on 26 % of arguments).  The solver itself (status, iteration count, J, x) uses
+none of them and stays bit-exact."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+LIBM = {"f_exp", "f_log", "f_sin", "f_minus_sin", "f_cos", "f_minus_cos", "f_atan", "f_srelu", "f_dsrelu", "f_ddsrelu",
+        "f_Dsqrt", "f_DDsqrt"}
+
+
+def _ulps(a, b):
+    return np.abs(a - b) / np.spacing(np.maximum(np.abs(a), np.abs(b)))
+
+
+@pytest.mark.parametrize("variant", ["strict", "w8x", "interp", "ldsm"])
+def test_opcode_zoo(tmp_path, variant):
+    import __graft_entry__ as g
+    from tenscalc_amd.problems.small import opcode_zoo
+    from tenscalc_amd.runtime import HipSolver
+    from tenscalc_amd.tapeio import save_tape
+    from oracle.tc_oracle import Oracle
+    spec = opcode_zoo(folder=g.GENERATED)
+    so = spec.build(**g.VARIANT_KW[variant])
+    B = 200
+    rs = np.random.RandomState(21)
+    A = rs.random_sample((B, 12, 4)); b = rs.random_sample((B, 12)); x0 = .02 * rs.random_sample((B, 4)) + .005
+    At = np.ascontiguousarray(np.transpose(A, (0, 2, 1)))
+    tape = str(tmp_path / "zoo.tape")
+    save_tape(spec.tape, tape)
+    c = spec.classname
+    ref, rst, rit = Oracle(tape).solve_batch({c + "_set_A": At.reshape(B, -1), c + "_set_b": b, c + "_set_x": x0},
+                                             c + "_getOutputs", B, mu0=1e-2, maxIter=40)
+    obj = HipSolver(so, B=B, device=0)
+    obj.setP_A(At); obj.setP_b(b); obj.setV_x(x0)
+    st, it, _ = obj.solve(mu0=1e-2, maxIter=40)
+    out = obj.getOutputs(as_dict=True)
+    assert np.array_equal(st, rst) and np.array_equal(it, rit) and (st == 0).all()
+    off, worst = 0, {}
+    for nm, sz in spec.outputs:
+        k = int(np.prod(sz)) if len(sz) else 1
+        got, want = out[nm].reshape(B, k), ref[:, off:off + k]
+        off += k
+        if nm in LIBM:
+            u = _ulps(got, want).max()
+            worst[nm] = u
+            assert u <= 4, (nm, u)
+        else:
+            assert np.array_equal(got, want), nm
+    print("\\n%s: worst ulp distance of the libm-based outputs:" % variant, {k: float(v) for k, v in worst.items()})
+    assert len(worst) == len(LIBM)
+
+
+def test_class_from_reference_dialect_cg_files(tmp_path, sls_spec):
+    """tape -> files as the reference's saveScalarized writes them -> load_cg -> HIP class -> solve: the same bits as
+    the oracle running the original tape (a MATLAB install hands any tape to the HIP back-end)"""
+    from tenscalc_amd.cgformat import save_cg
+    from tenscalc_amd.problems.sls import SOLVE_ARGS, sls_batch
+    from tenscalc_amd.runtime import HipSolver
+    from tenscalc_amd.tapeio import save_tape
+    from tenscalc_amd.tools.build_class import spec_from_cg
+    from oracle.tc_oracle import Oracle
+    base = str(tmp_path / "slsref")
+    save_cg(sls_spec.tape, base, word=32, extensions="opcodes")
+    spec2 = spec_from_cg(base, defines=sls_spec.defines, folder=str(tmp_path))
+    assert spec2.classname == sls_spec.classname and [nm for nm, _ in spec2.parameters] == ["A", "b", "x"]
+    so = spec2.build(fp_contract="off", tag="fromcg", static_clean=True)
+    B = 300
+    A, b, x0 = sls_batch(B, seed0=8100)
+    obj = HipSolver(so, B=B, device=0)
+    obj.set("A", np.ascontiguousarray(np.transpose(A, (0, 2, 1))))
+    obj.set("b", b)
+    obj.set("x", x0)
+    st, it, _ = obj.solve(**SOLVE_ARGS)
+    got = np.concatenate([a.reshape(B, -1) for a in obj.getOutputs()], axis=1)
+    tape = str(tmp_path / "orig.tape")
+    save_tape(sls_spec.tape, tape)
+    c = sls_spec.classname
+    ref, rst, rit = Oracle(tape).solve_batch({c + "_set_A": np.transpose(A, (0, 2, 1)).reshape(B, -1), c + "_set_b": b,
+                                              c + "_set_x": x0}, c + "_getOutputs", B, mu0=SOLVE_ARGS["mu0"],
+                                             maxIter=SOLVE_ARGS["maxIter"])
+    assert np.array_equal(st, rst) and np.array_equal(it, rit) and np.array_equal(got, ref)
