@@ -122,71 +122,34 @@ def main():
     O = torch.as_tensor(_DevArray(optr, (9, B), "<f8"), device=dev)
     ST = torch.as_tensor(_DevArray(sptr, (B,), "<i4"), device=dev)
     IT = torch.as_tensor(_DevArray(iptr, (B,), "<i4"), device=dev)
-    from tenscalc_amd.sharding import pack_results
-    # the path's only exchange: results (J, x, status, iter) of every rank gathered on every rank.  It overlaps
-    # the next step's solve: the results are packed on the launch stream into one of two buffers, the collective
-    # is enqueued asynchronously (RCCL runs it on its own stream after the pack) and is only waited for when its
-    # buffer comes up for reuse -- and, for all of them, before the timed region ends.
-    gathered = [torch.empty((world, 11, B), dtype=torch.float64, device=cdev) for _ in range(2)] if world > 1 else None
-    packed = [None, None]
-    pending = [None, None]
-    nex = [0]
-
-    def exchange():
-        k = nex[0] & 1
-        nex[0] += 1
-        if pending[k] is not None:
-            pending[k].wait()
-        packed[k] = pack_results(O, ST, IT).to(cdev).contiguous()
-        pending[k] = dist.all_gather_into_tensor(gathered[k].view(world * 11, B), packed[k], async_op=True)
-
-    def drain():
-        for k in range(2):
-            if pending[k] is not None:
-                pending[k].wait()
-                pending[k] = None
-
+    from tenscalc_amd.sharding import ResultExchange, pack_results, reduce_timing, run_timed
+    # the path's only exchange: results (J, x, status, iter) of every rank gathered on every rank -- ONE gather after
+    # the K steps by default; with --gather-every-step after every step, overlapped with the next
+    # step's solve (packed on the launch stream, the collective asynchronous on RCCL's own stream).  The control
+    # flow is tenscalc_amd/sharding.py:run_timed, rehearsed with gloo on the CPU by tests/test_sharding_gloo.py.
     every = world > 1 and args.gather_every_step
+    xch = ResultExchange(world, (11, B), cdev) if world > 1 else None
 
-    def step():
+    def solve(_k=0):
         obj.solve_async(SOLVE_ARGS["mu0"], SOLVE_ARGS["maxIter"], SOLVE_ARGS["addEye2Hessian"], stream=stream)
-        if every:
-            exchange()
 
     for _ in range(args.warmup):
-        step()
-    if world > 1:
-        drain()
-    # --- timed region: barrier + synchronize on both sides, exactly K steps
-    kern_ms = []
-    evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
-    if world > 1:
-        bar()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for k in range(args.steps):
-        evs[k][0].record()
-        obj.solve_async(SOLVE_ARGS["mu0"], SOLVE_ARGS["maxIter"], SOLVE_ARGS["addEye2Hessian"], stream=stream)
-        evs[k][1].record()
+        solve()
         if every:
-            exchange()
+            xch.exchange(pack_results(O, ST, IT))
     if world > 1:
-        if not every:
-            exchange()             # the path's only exchange: ONE gather of the results, after the K steps
-        drain()                    # ... completed inside the timed region
-    torch.cuda.synchronize()
-    if world > 1:
-        bar()
-        torch.cuda.synchronize()
-    elapsed = time.perf_counter() - t0
+        xch.drain()
+    # --- timed region: barrier + synchronize on both sides, exactly K steps
+    evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
+
+    def step(k):
+        evs[k][0].record()
+        solve()
+        evs[k][1].record()
+    elapsed = run_timed(args.steps, step, lambda: pack_results(O, ST, IT), world, every=every,
+                        barrier=bar, sync=torch.cuda.synchronize, exchange=xch)
     kern_ms = [a.elapsed_time(b_) for a, b_ in evs]          # events on the launch stream
-    el = torch.tensor([elapsed], dtype=torch.float64, device=cdev)
-    ok = (ST == 0).sum().to(torch.float64).reshape(1).to(cdev)
-    if world > 1:
-        dist.all_reduce(el, op=dist.ReduceOp.MAX)
-        dist.all_reduce(ok, op=dist.ReduceOp.SUM)
-    elapsed = float(el.item())
-    solved_per_step = float(ok.item())                        # only status==0 instances count
+    elapsed, solved_per_step = reduce_timing(elapsed, int((ST == 0).sum().item()), world, cdev)   # only status==0 count
     value = solved_per_step * args.steps / elapsed
 
     out = None

@@ -42,3 +42,79 @@ def unpack_results(gathered, n_out):
     W, R, B = gathered.shape
     g = gathered.permute(1, 0, 2).reshape(R, W * B)
     return g[:n_out], g[n_out].to(torch.int32), g[n_out + 1].to(torch.int32)
+
+
+class ResultExchange:
+    """The path's only exchange, as bench.py runs it for N > 1: every rank contributes its packed results
+    ([R, B] float64) and receives everybody's.  Double buffered and asynchronous: a gather is enqueued right after
+    the step that produced the results and is only waited for when its buffer comes up for reuse -- or, for all of
+    them, by drain() before the timed region ends."""
+
+    def __init__(self, world, shape, device, dtype=None):
+        import torch
+        self.world = int(world)
+        self.gathered = [torch.empty((self.world,) + tuple(shape), dtype=dtype or torch.float64, device=device)
+                         for _ in range(2)]
+        self.packed = [None, None]
+        self.pending = [None, None]
+        self.count = 0
+        self.device = device
+
+    def exchange(self, packed):
+        import torch.distributed as dist
+        k = self.count & 1
+        self.count += 1
+        if self.pending[k] is not None:
+            self.pending[k].wait()
+        self.packed[k] = packed.to(self.device).contiguous()       # kept alive until the collective has run
+        g = self.gathered[k]
+        self.pending[k] = dist.all_gather_into_tensor(g.view(self.world * g.shape[1], g.shape[2]), self.packed[k],
+                                                      async_op=True)
+
+    def drain(self):
+        for k in range(2):
+            if self.pending[k] is not None:
+                self.pending[k].wait()
+                self.pending[k] = None
+
+    def last(self):
+        """[world, R, B] of the most recent exchange (after drain())"""
+        return self.gathered[(self.count - 1) & 1] if self.count else None
+
+
+def run_timed(steps, step, results, world, every=False, barrier=None, sync=None, exchange=None):
+    """bench.py's timed region: barrier + sync, exactly `steps` calls of step(k), the result gather(s) -- after every
+    step (`every`) or ONE after the last step -- drained, sync + barrier; returns the local elapsed
+    seconds.  results() -> the rank's packed results tensor; exchange: a ResultExchange (world > 1)."""
+    import time
+    barrier = barrier or (lambda: None)
+    sync = sync or (lambda: None)
+    if world > 1:
+        barrier()
+    sync()
+    t0 = time.perf_counter()
+    for k in range(steps):
+        step(k)
+        if world > 1 and every:
+            exchange.exchange(results())
+    if world > 1:
+        if not every:
+            exchange.exchange(results())
+        exchange.drain()
+    sync()
+    if world > 1:
+        barrier()
+        sync()
+    return time.perf_counter() - t0
+
+
+def reduce_timing(elapsed, solved, world, device):
+    """(max elapsed over ranks, total solved instances over ranks): what rank 0 reports"""
+    import torch
+    import torch.distributed as dist
+    el = torch.tensor([float(elapsed)], dtype=torch.float64, device=device)
+    ok = torch.tensor([float(solved)], dtype=torch.float64, device=device)
+    if world > 1:
+        dist.all_reduce(el, op=dist.ReduceOp.MAX)
+        dist.all_reduce(ok, op=dist.ReduceOp.SUM)
+    return float(el.item()), float(ok.item())

@@ -78,3 +78,64 @@ def test_shard_range_partitions_everything():
             assert all(r[k][1] == r[k + 1][0] for k in range(world - 1))
             sizes = [hi - lo for lo, hi in r]
             assert max(sizes) - min(sizes) <= 1
+
+
+def _bench_flow_worker(rank, world, port, every, steps, q):
+    """bench.py's N>1 control flow (tenscalc_amd/sharding.py: run_timed + ResultExchange + reduce_timing) with the
+    per-rank solve replaced by a stand-in that produces recognisable results"""
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from tenscalc_amd.sharding import ResultExchange, reduce_timing, run_timed
+    B, R = 5, 4
+    state = dict(k=-1, calls=0)
+
+    def step(k):
+        state["k"] = k
+        state["calls"] += 1
+        if rank == 1:
+            import time
+            time.sleep(.01)                      # the slower rank sets the reported time
+
+    def results():
+        return torch.full((R, B), float(100 * rank + state["k"]), dtype=torch.float64)
+    xch = ResultExchange(world, (R, B), torch.device("cpu"))
+    seen = []
+    orig = xch.exchange
+
+    def counting(p):
+        seen.append(float(p[0, 0]))
+        orig(p)
+    xch.exchange = counting
+    el = run_timed(steps, step, results, world, every=every, barrier=dist.barrier, exchange=xch)
+    elapsed, ok = reduce_timing(el, 3 + rank, world, torch.device("cpu"))
+    q.put((rank, state["calls"], seen, xch.last().clone().numpy(), el, elapsed, ok))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("every", [False, True])
+def test_bench_multi_rank_control_flow(every):
+    """world_size 2 over gloo: exactly K steps per rank; ONE gather after the K steps by default, one per
+    step (double-buffered, drained before the clock stops) with --gather-every-step; every rank ends with everybody's
+    last results; the reported time is the MAX over ranks and the solved count the SUM"""
+    world, steps = 2, 5
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_bench_flow_worker, args=(r, world, port, every, steps, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = sorted(q.get(timeout=120) for _ in range(world))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for rank, calls, seen, last, el, elapsed, ok in res:
+        assert calls == steps
+        assert seen == ([100.0 * rank + k for k in range(steps)] if every else [100.0 * rank + steps - 1])
+        assert last.shape == (world, 4, 5)
+        assert (last[0] == steps - 1).all() and (last[1] == 100 + steps - 1).all()      # everybody's LAST results
+        assert ok == 3 + 4
+    assert res[0][5] == res[1][5] == max(res[0][4], res[1][4])                            # max over ranks
+    assert res[1][4] >= steps * .01
