@@ -54,6 +54,14 @@ GET1(getNorminf_G__)
 GET1(getNorminf_Grad__)
 GET1(getCurvature__)
 GET1(getMinF_s__)
+GET1(getMinF_a__)
+GET1(getRho__)
+static inline void getMaxAlphas_a__(TcCtx &c, double *alphaPrimal, double *alphaDual) {
+  double t[2];
+  tco_get_flat(c.g, traced(c.g, "getMaxAlphas_a__"), t);
+  *alphaPrimal = t[0];
+  *alphaDual = t[1];
+}
 static inline void getGapMinFMinLambda__(TcCtx &c, double *gap, double *ineq, double *dual) {
   double t[3];
   tco_get_flat(c.g, traced(c.g, "getGapMinFMinLambda__"), t);

@@ -36,6 +36,14 @@ GET1(getNorminf_G__)
 GET1(getNorminf_Grad__)
 GET1(getCurvature__)
 GET1(getMinF_s__)
+GET1(getMinF_a__)   /* skipAffine=0 builds (lib/ipmPD_CS.m assembly): predictor step, ipmPD_CSsolver.c:576-665 */
+GET1(getRho__)
+void getMaxAlphas_a__(double *alphaPrimal, double *alphaDual) {
+  double t[2];
+  tco_get_flat(g, tco_entry(g, "getMaxAlphas_a__"), t);
+  *alphaPrimal = t[0];
+  *alphaDual = t[1];
+}
 void getGapMinFMinLambda__(double *gap, double *ineq, double *dual) {
   double t[3];
   tco_get_flat(g, tco_entry(g, "getGapMinFMinLambda__"), t);

@@ -57,7 +57,7 @@ struct tco {
       e_initDualEqX, e_setAddEyeU, e_setAddEyeEq, e_getNorminfGrad, e_getNorminfG,
       e_getGapMinFMinLambda, e_getCurvature, e_getHessInertia, e_getDirectionError,
       e_getMaxAlphas_s, e_getMinF_s, e_setAlphaPrimal, e_setAlphaDualEq, e_setAlphaDualIneq,
-      e_updatePrimalDual, e_getJ;
+      e_updatePrimalDual, e_getJ, e_getMaxAlphas_a, e_getMinF_a, e_getRho;
   /* statistics */
   int64_t flops, groupEvals, minFtrials;
 };
@@ -205,6 +205,8 @@ tco_t *tco_load(const char *path) {
   d->muFactorAggressive = define(t, "muFactorAggressive", .2);
   d->muFactorConservative = define(t, "muFactorConservative", .95);
   d->skipAffine = (int)define(t, "skipAffine", 1);
+  d->smallerNewtonMatrix = (int)define(t, "smallerNewtonMatrix", 0);
+  d->delta = (int)define(t, "delta", 3);
 #define E(field, name) t->field = tco_entry(t, name)
   E(e_initPrimal, "initPrimal__");
   E(e_scaleIneq, "scaleIneq__");
@@ -223,6 +225,9 @@ tco_t *tco_load(const char *path) {
   E(e_getDirectionError, "getDirectionError__");
   E(e_getMaxAlphas_s, "getMaxAlphas_s__");
   E(e_getMinF_s, "getMinF_s__");
+  E(e_getMaxAlphas_a, "getMaxAlphas_a__");
+  E(e_getMinF_a, "getMinF_a__");
+  E(e_getRho, "getRho__");
   E(e_setAlphaPrimal, "setAlphaPrimal__");
   E(e_setAlphaDualEq, "setAlphaDualEq__");
   E(e_setAlphaDualIneq, "setAlphaDualIneq__");
@@ -507,9 +512,9 @@ static void getMinF(tco_t *t, double *a) {
   tco_get_flat(t, t->e_getMinF_s, a);
 }
 
-/* ipmPD_CSsolver(), lib/ipmPD_CSsolver.c:132-1000, for skipAffine=1 (the only variant
- * cmex2optimizeCS generates, cmex2optimizeCS.m:83-95).  Compile-time #if's of the template
- * become run-time tests on tco_defines_t. */
+/* ipmPD_CSsolver(), lib/ipmPD_CSsolver.c:132-1000: skipAffine=1 (the variant cmex2optimizeCS generates,
+ * cmex2optimizeCS.m:83-95) and skipAffine=0 / smallerNewtonMatrix (lib/ipmPD_CS.m assembly: Mehrotra predictor
+ * step :576-665).  Compile-time #if's of the template become run-time tests on tco_defines_t. */
 void tco_solve(tco_t *t, double mu0, int32_t maxIter, int32_t saveIter, const double *addEye2Hessian,
                int32_t *status, int32_t *iter) {
   const tco_defines_t *d = &t->d;
@@ -520,7 +525,8 @@ void tco_solve(tco_t *t, double mu0, int32_t maxIter, int32_t saveIter, const do
   double derr = 0, curvature = 0, mp = 0, mn = 0, tmp[4];
   int updateAddEye2HessianU = 0, updateAddEye2HessianEq = 0;
   const int adjust = d->setAddEye2Hessian && d->adjustAddEye2Hessian;
-  const double mpDesired = d->nU, mnDesired = nF + nG; /* :164-169 */
+  const double mpDesired = d->nU, mnDesired = d->smallerNewtonMatrix ? nG : nF + nG; /* :164-169 */
+  double sigma = 0;
   double norminf_grad, scale4cost, alphaMax_ = d->alphaMax;
   double mu = mu0, stepback = .99, muMin = 0, gap = 0, ineq = 0, ineq1 = 0, dual = 0,
          desiredDualityGapVar = d->desiredDualityGap, alphaPrimal = 0, alphaDualEq = 0,
@@ -672,6 +678,55 @@ void tco_solve(tco_t *t, double mu0, int32_t maxIter, int32_t saveIter, const do
       if (nG > 0) tco_set(t, t->e_setAlphaDualEq, &alphaMax_);
       tco_copy(t, t->e_updatePrimalDual);
     } else {
+      if (!d->skipAffine) { /* affine search direction :576-665 */
+        tco_get_flat(t, t->e_getMaxAlphas_a, tmp);
+        alphaPrimal = tmp[0];
+        alphaDualIneq = tmp[1];
+        alphaMax_ = (alphaPrimal < d->alphaMax) ? alphaPrimal : d->alphaMax;
+        if (alphaDualIneq < alphaMax_) alphaMax_ = alphaDualIneq;
+        if (alphaMax_ >= d->alphaMin) {
+          alphaPrimal = alphaMax_; /* try max */
+          tco_set(t, t->e_setAlphaPrimal, &alphaPrimal);
+          get1(t, t->e_getMinF_a, &ineq);
+          if (ineq < 0) {
+            alphaPrimal = d->alphaMin; /* try min */
+            tco_set(t, t->e_setAlphaPrimal, &alphaPrimal);
+            get1(t, t->e_getMinF_a, &ineq);
+            if (ineq > 0) { /* try between min and max */
+              for (alphaPrimal = alphaMax_ * .95; alphaPrimal >= d->alphaMin; alphaPrimal /= 2) {
+                tco_set(t, t->e_setAlphaPrimal, &alphaPrimal);
+                get1(t, t->e_getMinF_a, &ineq);
+                if (ineq >= 0) break;
+              }
+              if (alphaPrimal < d->alphaMin) {
+                alphaPrimal = 0;
+                tco_set(t, t->e_setAlphaPrimal, &alphaPrimal);
+              }
+            } else {
+              alphaPrimal = 0;
+              tco_set(t, t->e_setAlphaPrimal, &alphaPrimal);
+            }
+          }
+        } else {
+          alphaPrimal = 0;
+          tco_set(t, t->e_setAlphaPrimal, &alphaPrimal);
+        }
+        tco_set(t, t->e_setAlphaDualIneq, &alphaPrimal);
+        /* update mu based on sigma :636-664 */
+        if (alphaPrimal > d->alphaMax / 2 &&
+            (nG == 0 || norminf_eq < 100 * d->equalTolerance || norminf_eq < 1e-3)) {
+          get1(t, t->e_getRho, &sigma);
+          if (sigma > 1) sigma = 1;
+          if (sigma < 0) sigma = 0;
+          if (d->delta == 2)
+            sigma = sigma * sigma;
+          else
+            sigma = sigma * sigma * sigma;
+          mu = sigma * gap / nF;
+          if (mu < muMin) mu = muMin;
+          tco_set(t, t->e_setMu, &mu);
+        }
+      }
       /* combined search direction :679-772 */
       tco_get_flat(t, t->e_getMaxAlphas_s, tmp);
       alphaPrimal = tmp[0];
@@ -736,7 +791,9 @@ void tco_solve(tco_t *t, double mu0, int32_t maxIter, int32_t saveIter, const do
       /* mu update, skipAffine!=0 :782-847 */
       int th_grad = norminf_grad < MAX(1e-6, 1e0 * d->gradTolerance);
       int th_eq = nG > 0 ? norminf_eq < MAX(1e-5, 1e0 * d->equalTolerance) : 1;
-      if (alphaPrimal > alphaMax_ / 2 && th_grad && th_eq) {
+      if (!d->skipAffine) {
+        /* :848-850: the predictor step has already chosen mu */
+      } else if (alphaPrimal > alphaMax_ / 2 && th_grad && th_eq) {
         mu *= MIN(d->muFactorAggressive, pow(mu, .5));
         if (mu < muMin) mu = muMin;
         tco_set(t, t->e_setMu, &mu);

@@ -17,6 +17,8 @@ typedef struct {
   int coupledAlphas, setAddEye2Hessian, adjustAddEye2Hessian, useInertia;
   double muFactorAggressive, muFactorConservative;
   int skipAffine;
+  int smallerNewtonMatrix; /* ipmPD_CS.m only: the inequality duals are eliminated from the Newton system */
+  int delta;               /* exponent of sigma in the Mehrotra mu update (ipmPD_CSsolver.c:650-654) */
 } tco_defines_t;
 
 tco_t *tco_load(const char *tapePath);

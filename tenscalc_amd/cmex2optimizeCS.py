@@ -15,7 +15,7 @@ import re
 
 from . import tcalculus as tc
 from .csparse import CSparse
-from .ipm_assembly import ipmPD_CStimesLambda
+from .ipm_assembly import ipmPD_CS, ipmPD_CStimesLambda
 from .tcalculus import Tvariable, Tzeros, cat, reshape, substitute
 
 __all__ = ["cmex2optimizeCS", "SolverSpec"]
@@ -97,8 +97,13 @@ def cmex2optimizeCS(*, classname, objective, optimizationVariables, constraints=
                     delta=3, alphaMin=1e-7, alphaMax=1.0, coupledAlphas=True,
                     addEye2Hessian=True, adjustAddEye2Hessian=True, useInertia=False,
                     addEye2HessianUtolerance=1e-6, smallerNewtonMatrix=False, useLDL=True,
-                    useUmfpack=False, allowSave=False, solverVerboseLevel=0, hoist=False, **ignored):
+                    useUmfpack=False, allowSave=False, solverVerboseLevel=0, hoist=False, lambdaUpdate="multiplicative",
+                    **ignored):
     """Generate an interior-point solver for ``min objective s.t. constraints``.
+
+    ``lambdaUpdate='additive'`` generates the reference's original assembly lib/ipmPD_CS.m (``switch 1`` at
+    cmex2optimizeCS.m:84-93) instead of ipmPD_CStimesLambda.m; only with it are ``skipAffine=False`` (Mehrotra
+    predictor step, ipmPD_CSsolver.c:576-665) and ``smallerNewtonMatrix=True`` available.
 
     ``hoist=True`` (not a reference option) applies tenscalc_amd/hoist.py: products of
     parameter-only factors in the derivatives are contracted first, so they are evaluated once
@@ -116,10 +121,14 @@ def cmex2optimizeCS(*, classname, objective, optimizationVariables, constraints=
         bad = sorted(set(ignored) - accepted_noop)
         if bad:
             raise TypeError("cmex2optimizeCS: unknown option(s) %s" % ", ".join(bad))
-    if not skipAffine:
-        raise NotImplementedError("skipAffine=false not implemented (ipmPD_CStimesLambda.m:37-39)")
-    if smallerNewtonMatrix:
-        raise NotImplementedError("smallerNewtonMatrix=true not implemented (ipmPD_CStimesLambda.m:34-36)")
+    if lambdaUpdate not in ("multiplicative", "additive"):
+        raise ValueError("lambdaUpdate: 'multiplicative' (ipmPD_CStimesLambda.m, what cmex2optimizeCS.m:92 selects) "
+                         "or 'additive' (ipmPD_CS.m, cmex2optimizeCS.m:86)")
+    if lambdaUpdate == "multiplicative":
+        if not skipAffine:
+            raise NotImplementedError("skipAffine=false needs lambdaUpdate='additive' (ipmPD_CStimesLambda.m:37-39)")
+        if smallerNewtonMatrix:
+            raise NotImplementedError("smallerNewtonMatrix=true needs lambdaUpdate='additive' (ipmPD_CStimesLambda.m:34-36)")
     if not useLDL or useUmfpack:
         raise NotImplementedError("only the LDL path is implemented (ipmPD_CStimesLambda.m:40-45)")
     if allowSave:
@@ -168,9 +177,14 @@ def cmex2optimizeCS(*, classname, objective, optimizationVariables, constraints=
     if hoist:
         from .hoist import Hoister
         rewrite = Hoister(parameters).rewrite
-    Tout = ipmPD_CStimesLambda(code, u, objective_u, F, G, lam, nu,
-                               addEye2Hessian=addEye2Hessian, scaleCost=scaleCost,
-                               scaleInequalities=scaleInequalities, classname=classname, rewrite=rewrite)
+    if lambdaUpdate == "additive":
+        Tout = ipmPD_CS(code, u, objective_u, F, G, lam, nu, addEye2Hessian=addEye2Hessian, scaleCost=scaleCost,
+                        scaleInequalities=scaleInequalities, classname=classname, rewrite=rewrite,
+                        skipAffine=bool(skipAffine) or nF == 0, smallerNewtonMatrix=bool(smallerNewtonMatrix))
+    else:
+        Tout = ipmPD_CStimesLambda(code, u, objective_u, F, G, lam, nu,
+                                   addEye2Hessian=addEye2Hessian, scaleCost=scaleCost,
+                                   scaleInequalities=scaleInequalities, classname=classname, rewrite=rewrite)
     # outputs may refer to internal quantities through '<field>_' variables (cmex2optimizeCS.m:265-271)
     for fn, val in Tout.items():
         ph = Tvariable(fn + "_", val.size)
@@ -191,7 +205,7 @@ def cmex2optimizeCS(*, classname, objective, optimizationVariables, constraints=
         coupledAlphas=int(bool(coupledAlphas)), setAddEye2Hessian=int(bool(addEye2Hessian)),
         adjustAddEye2Hessian=int(bool(adjustAddEye2Hessian)), useInertia=int(bool(useInertia)),
         muFactorAggressive=float(muFactorAggressive), muFactorConservative=float(muFactorConservative),
-        delta=int(delta), skipAffine=1, smallerNewtonMatrix=0, useLDL=1, useUmfpack=0, allowSave=0,
+        delta=int(delta), skipAffine=int(bool(skipAffine) or nF == 0), smallerNewtonMatrix=int(bool(smallerNewtonMatrix)), useLDL=1, useUmfpack=0, allowSave=0,
         debugConvergence=0, profiling=0, verboseLevel=int(solverVerboseLevel))
     tape = code.compile(defines)
     spec = SolverSpec(classname, tape, defines,

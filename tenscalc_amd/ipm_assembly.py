@@ -166,3 +166,164 @@ def ipmPD_CStimesLambda(code, u, f, F, G, lam, nu, *, addEye2Hessian=True, scale
     code.declareCopy(dsts, srcs, "updatePrimalDual__")
     out["b"], out["dx"] = b, dx
     return out
+
+
+def ipmPD_CS(code, u, f, F, G, lam, nu, *, addEye2Hessian=True, scaleCost=0.0, scaleInequalities=True,
+             classname="cls", skipAffine=True, smallerNewtonMatrix=False, rewrite=None):
+    """The reference's ORIGINAL assembly, /root/reference/lib/ipmPD_CS.m (packOptimizationVariables=true, LDL, no
+    trust region): ADDITIVE update of lambda, optional Mehrotra predictor ("affine") step -- skipAffine=False:
+    entry points getMaxAlphas_a__, getMinF_a__, getRho__ for lib/ipmPD_CSsolver.c:576-665 -- and optional
+    elimination of the inequality duals from the Newton system (smallerNewtonMatrix, :249-333: a (nU+nG) square
+    system instead of nU+nG+nF).  cmex2optimizeCS.m:83-95 hard-selects ipmPD_CStimesLambda (``switch 3``); this is
+    what ``switch 1`` there generates."""
+    out = {}
+    rw = rewrite if rewrite is not None else (lambda e: e)
+    nU = u.size[0]
+    nG = G.size[0] if G.ndim else 0
+    nF = F.size[0] if F.ndim else 0
+    if nF > 0 and scaleInequalities:                                        # :90-97
+        scale4Ineq = Tvariable("scale4Ineq__", F.size)
+        code.declareCopy(scale4Ineq, tabs(rdivide(1.0, F)), "scaleIneq__")
+        F = times(scale4Ineq, F)
+    if scaleCost > 0:                                                       # :98-107
+        scale4Cost = Tvariable("scale4Cost__", ())
+        code.declareCopy(scale4Cost, tabs(rdivide(float(scaleCost), f)), "scaleCost__")
+        f = scale4Cost * f
+        code.declareGet(scale4Cost, "getScale4Cost__")
+    out["u"], out["F"], out["G"], out["nu"], out["lambda"] = u, F, G, nu, lam
+    code.declareGet(rw(f), "getJ__")
+    if addEye2Hessian:                                                      # :128-137
+        addEye2HessianU = Tvariable("addEye2HessianU__", ())
+        addEye2HessianEq = Tvariable("addEye2HessianEq__", ())
+        code.declareSet(addEye2HessianU, "setAddEye2HessianU__")
+        code.declareSet(addEye2HessianEq, "setAddEye2HessianEq__")
+    else:
+        addEye2HessianU = Tzeros(())
+        addEye2HessianEq = Tzeros(())
+    f_u = rw(gradient(f, u))                                                # :146-200
+    Lf = f
+    if nF > 0:
+        F_u = rw(gradient(F, u))
+        gap = tprod(lam, (-1,), F, (-1,))
+        Lf = Lf - gap
+    else:
+        F, F_u, gap = Tzeros((0,)), Tzeros((0, nU)), Tzeros(())
+    if nG > 0:
+        G_u = rw(gradient(G, u))
+        Lf = Lf + tprod(nu, (-1,), G, (-1,))
+    else:
+        G, G_u = Tzeros((0,)), Tzeros((0, nU))
+    Lf_uu, Lf_u = hessian(Lf, u)
+    Lf_uu, Lf_u = rw(Lf_uu), rw(Lf_u)
+    out["Lf_u"], out["Lf_uu"] = Lf_u, Lf_uu
+    code.declareGet(Lf_u, "getGrad__")
+    code.declareGet(norminf(Lf_u), "getNorminf_Grad__")
+    if nF > 0:                                                              # :207-218
+        mu = Tvariable("mu__", ())
+        muOnes = tc.expand(mu, (nF,))
+        code.declareSet(mu, "setMu__")
+        code.declareCopy(lam, rdivide(muOnes, F), "initDualIneq__")
+        code.declareGet([gap, tmin(F, 1), tmin(lam, 1)], "getGapMinFMinLambda__")
+    else:
+        mu, muOnes = Tzeros(()), Tzeros((0,))
+    out["mu"] = mu
+    if nG > 0:                                                              # :219-234
+        code.declareCopy(nu, Tones((nG,)), "initDualEq__")
+        WW0 = cat(1, cat(2, Teye((nU, nU)), transpose(G_u)),
+                  cat(2, G_u, -(addEye2HessianEq * Teye((nG, nG)))))
+        factor_ww0 = ldl(WW0, classname + "_WW0", stages=[0] * nU + [1] * nG)
+        b0 = cat(1, (transpose(F_u) * lam if nF > 0 else Tzeros((nU,))) - f_u, Tzeros((nG,)))
+        code.declareCopy(nu, full(mldivide(factor_ww0, b0))[nU:nU + nG], "initDualEqX__")
+        code.declareGet(norminf(G), "getNorminf_G__")
+    alphaPrimal = Tvariable("alphaPrimal__", ())
+    code.declareSet(alphaPrimal, "setAlphaPrimal__")
+    alphaDualEq = Tvariable("alphaDualEq__", ())
+    code.declareSet(alphaDualEq, "setAlphaDualEq__")
+    alphaDualIneq = Tvariable("alphaDualIneq__", ())
+    code.declareSet(alphaDualIneq, "setAlphaDualIneq__")
+
+    def blocks(rows):
+        return cat(1, *[cat(2, *r) for r in rows if r])
+
+    def affine(dU_a, dLambda_a):
+        """entry points of the predictor step (:283-296 / :379-392)"""
+        newU_a = u + alphaPrimal * dU_a
+        newLambda_a = lam + alphaDualIneq * dLambda_a
+        newF_a = substitute(F, u, newU_a)
+        code.declareGet([clp(F, F_u * dU_a), clp(lam, dLambda_a)], "getMaxAlphas_a__")
+        code.declareGet(tmin(newF_a, 1), "getMinF_a__")
+        code.declareGet(rdivide(tprod(newF_a, (-1,), newLambda_a, (-1,)), gap), "getRho__")
+    Gnu = (tprod(G_u, (-1, 1), nu, (-1,)) if nG > 0 else Tzeros((nU,)))
+    if smallerNewtonMatrix:                                                 # :249-333
+        if nF == 0:
+            raise ValueError("smallerNewtonMatrix needs inequality constraints")
+        LPG = tprod(rdivide(lam, F), (1,), F_u, (1, 2))
+        WW11 = Lf_uu + tprod(F_u, (-1, 1), LPG, (-1, 2)) + addEye2HessianU * Teye((nU, nU))
+        rows = [[WW11], []]
+        if nG > 0:
+            rows[0].append(transpose(G_u))
+            rows[1] = [G_u, -(addEye2HessianEq * Teye((nG, nG)))]
+        WW = blocks(rows)
+        muF = rdivide(muOnes, F)
+        factor_ww = ldl(WW, classname + "_WW", stages=[0] * nU + [1] * nG)
+        tail = [-G] if nG > 0 else []
+        if skipAffine:
+            b_s = cat(1, -f_u - Gnu + tprod(F_u, (-1, 1), muF, (-1,)), *tail)
+        else:
+            b_a = cat(1, -f_u - Gnu, *tail)
+            dx_a = code.declareAlias(mldivide(factor_ww, b_a), "dUNu_a__")
+            dU_a = dx_a[0:nU]
+            dLambda_a = -(LPG * dU_a) - lam
+            affine(dU_a, dLambda_a)
+            Mehrotra = rdivide(times(F_u * dU_a, dLambda_a), F)
+            b_s = cat(1, -f_u - Gnu + tprod(F_u, (-1, 1), muF, (-1,)) - tprod(F_u, (-1, 1), Mehrotra, (-1,)), *tail)
+        dx_s = code.declareAlias(mldivide(factor_ww, b_s), "dx_s__")
+        dU_s = dx_s[0:nU]
+        dLambda_s = muF - LPG * dU_s - lam
+        if not skipAffine:
+            dLambda_s = dLambda_s - Mehrotra
+    else:                                                                   # :334-427
+        WW11 = Lf_uu + addEye2HessianU * Teye((nU, nU))
+        rows = [[WW11], [], []]
+        if nG > 0:
+            rows[0].append(transpose(G_u))
+            rows[1] = [G_u, -(addEye2HessianEq * Teye((nG, nG)))]
+        if nF > 0:
+            rows[0].append(-transpose(F_u))
+            if nG > 0:
+                rows[1].append(Tzeros((nG, nF)))
+            rows[2] = [-F_u] + ([Tzeros((nF, nG))] if nG > 0 else []) + [-diag(rdivide(F, lam))]
+        WW = blocks(rows)
+        factor_ww = ldl(WW, classname + "_WW", stages=[0] * nU + [1] * nG + [0] * nF)
+        mid = [-G] if nG > 0 else []
+        if skipAffine or nF == 0:
+            b_s = cat(1, -Lf_u, *mid, *([F - rdivide(muOnes, lam)] if nF > 0 else []))
+        else:
+            b_a = cat(1, -Lf_u, *mid, F)
+            dx_a = code.declareAlias(mldivide(factor_ww, b_a), "dUNu_a__")
+            dU_a = dx_a[0:nU]
+            dLambda_a = dx_a[nU + nG:nU + nG + nF]
+            affine(dU_a, dLambda_a)
+            b_s = cat(1, -Lf_u, *mid, F + rdivide(times(F_u * dU_a, dLambda_a), lam) - rdivide(muOnes, lam))
+        dx_s = code.declareAlias(mldivide(factor_ww, b_s), "dx_s__")
+        dU_s = dx_s[0:nU]
+        dLambda_s = dx_s[nU + nG:nU + nG + nF] if nF > 0 else None
+    out["Hess"] = WW
+    out["dHess"], out["lHess"] = ldl_d(factor_ww), ldl_l(factor_ww)
+    code.declareGet([tsum(compose(out["dHess"], "heaviside")), tsum(compose(-out["dHess"], "heaviside"))],
+                    "getHessInertia__")
+    code.declareGet([norminf(WW * dx_s - b_s)], "getDirectionError__")
+    code.declareGet(dU_s * (WW11 * dU_s), "getCurvature__")
+    dsts, srcs = [u], [u + alphaPrimal * dU_s]
+    if nG > 0:
+        dsts.append(nu)
+        srcs.append(nu + alphaDualEq * dx_s[nU:nU + nG])
+    if nF > 0:
+        newU_s = u + alphaPrimal * dU_s
+        code.declareGet([clp(F, F_u * dU_s), clp(lam, dLambda_s)], "getMaxAlphas_s__")
+        code.declareGet(tmin(substitute(F, u, newU_s), 1), "getMinF_s__")
+        dsts.append(lam)
+        srcs.append(lam + alphaDualIneq * dLambda_s)                         # ADDITIVE update (:315,408)
+    code.declareCopy(dsts, srcs, "updatePrimalDual__")
+    out["b"], out["dx"] = b_s, dx_s
+    return out

@@ -65,6 +65,11 @@ def newton_program(d):
             body.append(call("setAlphaDualEq__"))
         body.append(call("updatePrimalDual__"))
     else:
+        if not int(d.get("skipAffine", 1)):       # predictor step (ipm_newton.hip.inc, reference :580-664)
+            body.append(call("getMaxAlphas_a__"))
+            body.append(("loop", [call("setAlphaPrimal__"), ("if", [call("getMinF_a__")])]))
+            body.append(call("setAlphaDualIneq__"))
+            body.append(("if", [call("getRho__"), call("setMu__")]))
         body.append(call("getMaxAlphas_s__"))
         body.append(("loop", [call("setAlphaPrimal__"), ("if", [call("getMinF_s__")])]))
         if nG > 0:
