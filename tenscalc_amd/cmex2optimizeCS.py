@@ -196,6 +196,14 @@ def cmex2optimizeCS(*, classname, objective, optimizationVariables, constraints=
     outputExpressions = [tc.full(o) for o in outputExpressions]
     code.declareGet(outputExpressions, f"{classname}_getOutputs", list(outputNames))
 
+    # the reference passes the real-valued options to the C template through sprintf('%e') (cmex2optimizeCS.m:303-331):
+    # six significant digits.  The same rounding here, so that a non-default value such as muFactorAggressive=1/3
+    # gives the solver the reference would have generated (1e-4, .2, .95, ... are unchanged by it)
+    pe = lambda v: float("%e" % float(v))          # noqa: E731
+    gradTolerance, addEye2HessianUtolerance, equalTolerance, desiredDualityGap = (
+        pe(gradTolerance), pe(addEye2HessianUtolerance), pe(equalTolerance), pe(desiredDualityGap))
+    alphaMin, alphaMax, muFactorAggressive, muFactorConservative = (
+        pe(alphaMin), pe(alphaMax), pe(muFactorAggressive), pe(muFactorConservative))
     defines = dict(
         nU=u.size[0], nG=nG, nF=nF,
         gradTolerance=float(gradTolerance), addEye2HessianUtolerance=float(addEye2HessianUtolerance),
