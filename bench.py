@@ -71,8 +71,10 @@ def main():
     if args.config != "sls":
         return bench_config(args)
     args.variant = args.variant or "w8x"
-    if args.variant not in ("strict", "fast", "w8", "w8h", "regs", "regsl", "w8s", "w8x"):
-        ap.error("--variant for --config sls: strict, fast, w8, w8h, regs, regsl, w8s or w8x")
+    import __graft_entry__ as g
+    sls_variants = [v for v, kw in g.VARIANT_KW.items() if kw.get("body", "code") == "code"]
+    if args.variant not in sls_variants:
+        ap.error("--variant for --config sls: " + ", ".join(sls_variants))
 
     import numpy as np
     import torch

@@ -91,6 +91,7 @@ class Printer:
         self.exact = False
         self.stg_base = self.res_base = 0      # first LDS slot of the staging buffers / of the staged results
         self.stg_blocks = 1                    # row blocks (of P terms) staged per LDS round trip
+        self.ilp = False                       # print independent chains interleaved (see dfamily_body)
         self.stg_batch = 16                    # staged terms loaded back to back before their additions
         self._rv = {}               # slot -> index into c.rv[]: register copy that outlives the group (setup_rcache)
         self._fw_rep = {}           # slot -> name of the register copy (replicated values)
@@ -348,6 +349,31 @@ class Printer:
         L = self.L
         K = -(-f.n // L.P)
         out = []
+        t = f.template
+        if self.ilp and t.typ == I.I_sumprod and K > 1 and int(t.par[0]) * int(t.par[1]) < MAX_TERMS_PERLINE:
+            # the K rows of this lane are independent chains of multiply, add, multiply, add ...: printed row by
+            # row every instruction waits for the one before it (a dependent fp64 instruction issues after 8
+            # cycles, an independent one after 4: scripts/ubench/fp64_latency.hip).  Printed term by term ACROSS
+            # the rows -- same operations, same order within a row, same values -- the chains overlap.
+            nf, ns = int(t.par[0]), int(t.par[1])
+            rows = []
+            for k in range(K):
+                pos = [0]
+                r = []
+                for kid in t.kids:
+                    if isinstance(kid, Leaf):
+                        kind, v = f.leaves[pos[0]]
+                        pos[0] += 1
+                        r.append(self.vec_ref(v, k) if kind == "d" else self.leaf_text(v))
+                    else:
+                        r.append("(" + self._dexpr(kid, f, k, pos) + ")")
+                rows.append(["*".join(r[j * nf:(j + 1) * nf]) for j in range(ns)])
+            out.append("  {\n    double " + ", ".join(f"q{k}_ = {rows[k][0]}" for k in range(K)) + ";\n")
+            for j in range(1, ns):
+                out.append("    { const double " + ", ".join(f"p{k}_ = {rows[k][j]}" for k in range(K)) + ";\n     "
+                           + "".join(f" q{k}_ = q{k}_ + p{k}_;" for k in range(K)) + " }\n")
+            out.append("   " + "".join(f" c.dF{f.fid}[{k}] = q{k}_;" for k in range(K)) + "\n  }\n")
+            return "".join(out)
         for k in range(K):
             pos = [0]
             e = self._dexpr(f.template, f, k, pos)
@@ -944,7 +970,7 @@ def _mask(groups):
 def emit_class(spec, fp_contract="fast", block=64, stats=False, roll=True, min_waves=0, lanes=1,
                recip=False, fast_div=False, inline_max=0, reg_budget=150, scratch="auto", body="code",
                waves=1, fuse=False, static_clean=False, forward=False, rcache=0, lds_state=0, share=False,
-               branch_free_tails=True, exact=False, stg_blocks=0):
+               branch_free_tails=True, exact=False, stg_blocks=0, ilp=False):
     """Return the HIP source text of the solver class.
 
     exact=True (lanes>1, fp_contract='off', no recip/fast_div): the wave-cooperative lowering with the
@@ -993,6 +1019,7 @@ def emit_class(spec, fp_contract="fast", block=64, stats=False, roll=True, min_w
     P = Printer(L, roll=roll, recip=recip, fuse=fuse)
     P.forward = bool(forward) and lanes > 1
     P.exact = bool(exact) and lanes > 1
+    P.ilp = bool(ilp)
     if P.exact and (recip or fast_div or fuse or fp_contract != "off"):
         raise ValueError("exact=True needs fp_contract='off' and no recip/fast_div/fuse")
     P.branch_free_tails = bool(branch_free_tails)
@@ -1033,7 +1060,7 @@ def emit_class(spec, fp_contract="fast", block=64, stats=False, roll=True, min_w
         P.stg_base = nmp
         per_blk = lanes * (lanes + 1)
         kmax = max([-(-v[1] // lanes) for v in L.dreduce.values()], default=1)
-        room = (163840 // 4 // (block // lanes) // 8 - 8 - nmp) // per_blk
+        room = (163840 // (4 * max(1, int(min_waves))) // (block // lanes) // 8 - 8 - nmp) // per_blk
         P.stg_blocks = int(stg_blocks) if stg_blocks else max(1, min(kmax, room))
         rmax = {}
         for i_, v in L.dreduce.items():
@@ -1700,7 +1727,7 @@ def build_class(spec, fp_contract="fast", arch="gfx950", opt="-O3", block=64, fo
                 outdir=None, stats=False, tag=None, extra_flags=(), roll=True, min_waves=0, lanes=1,
                 recip=False, fast_div=False, inline_max=0, reg_budget=150, scratch="auto", body="code",
                 waves=1, fuse=False, static_clean=False, forward=False, rcache=0, lds_state=0, share=False,
-                branch_free_tails=True, exact=False, stg_blocks=0, lds_slots=20000):
+                branch_free_tails=True, exact=False, stg_blocks=0, lds_slots=20000, ilp=False):
     """Emit <cls>.hip (+ <cls>.h, <cls>.tape) and compile lib<cls>.so with hipcc for gfx950.
     Mirrors the createGateway/compile step of cmex2optimizeCS.m:403-417."""
     from .tapeio import save_tape
@@ -1717,7 +1744,7 @@ def build_class(spec, fp_contract="fast", arch="gfx950", opt="-O3", block=64, fo
                         min_waves=min_waves, lanes=lanes, recip=recip, fast_div=fast_div, inline_max=inline_max,
                         reg_budget=reg_budget, scratch=scratch, body=body, waves=waves, fuse=fuse,
                         static_clean=static_clean, forward=forward, rcache=rcache, lds_state=lds_state,
-                        share=share, branch_free_tails=branch_free_tails, exact=exact, stg_blocks=stg_blocks)
+                        share=share, branch_free_tails=branch_free_tails, exact=exact, stg_blocks=stg_blocks, ilp=ilp)
     hip = os.path.join(outdir, f"{cls}{suffix}.hip")
     so = os.path.join(outdir, f"lib{cls}{suffix}.so")
     flags = [opt, f"--offload-arch={arch}", "-fPIC", "-shared", "-std=c++17",
