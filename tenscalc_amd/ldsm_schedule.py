@@ -38,11 +38,13 @@ from . import instructions as I
 LANES = 64
 NSHORT = 8            # operands of a SHORT record
 K_SHORT, K_LONG, K_BARRIER, K_FOLD = 1, 0, 2, 3
+NLATE = 2              # late terms a FOLD record can compute itself (body rows 5..11: count, 2 x (position, 2 operands))
 OP_COPY = 60
 OP_CLPTERM = 61       # (b < 0) ? -a/b : DBL_MAX  -- one term of I_clp
 F_SUM = 3             # fold opcodes of K_FOLD records (the dot opcodes and I_sumprod keep their own number)
 STAGE = 2048          # staging slots for the terms of long instructions
 F_GLOBAL_SRC, F_GLOBAL_DST, F_NEW_LEVEL = 1, 2, 4
+F_NLATE_SHIFT = 3      # flags bits 3-4 of a FOLD record: the largest late-term count among its lanes
 _DOT_SKIP = {I.I_minus_dot: 0, I.I_minus_dot_div: 1, I.I_plus_minus_dot: 1, I.I_plus_minus_dot_div: 2}
 _LONG_OPS = {I.I_sum, I.I_sumprod, I.I_plus_sqr, I.I_plus_abs, I.I_min, I.I_min0, I.I_max, I.I_max0,
              I.I_max_abs, I.I_clp, I.I_minus_dot, I.I_minus_dot_div, I.I_plus_minus_dot, I.I_plus_minus_dot_div}
@@ -198,13 +200,20 @@ def _rec(words, headers, op, kind, n, aux, items, nLds, new_level):
         for j in range(n):
             words += pad([a[j] for _, a in items], items[-1][1][j])
         nn = n
-    elif kind == K_FOLD:                                     # items: (dest, [len, head0, head1, base])
-        for j in range(4):
+    elif kind == K_FOLD:      # items: (dest, [len, head0, head1, base (, nlate, NLATE x (position, operand, operand))])
+        rows = len(items[0][1])
+        if any(len(a) != rows for _, a in items):
+            raise AssertionError("fold record: mixed body shapes")
+        for j in range(rows):
             words += pad([a[j] for _, a in items], items[-1][1][j])
         nn = -(-max(a[0] for _, a in items) // 8) * 8
         flags &= ~F_GLOBAL_SRC
         if any((a[j] >> 1) >= nLds for _, a in items for j in (1, 2)):
             flags |= F_GLOBAL_SRC
+        if rows > 4:
+            flags |= max(a[4] for _, a in items) << F_NLATE_SHIFT
+            if any((a[j] >> 1) >= nLds for _, a in items for q in range(NLATE) for j in (6 + 3 * q, 7 + 3 * q)):
+                flags |= F_GLOBAL_SRC
     else:
         skip = _DOT_SKIP.get(op, 0)
         lens = [len(a) - skip for _, a in items]
@@ -228,7 +237,7 @@ _TERM = {  # long instruction -> (term opcode, operands per term, fold opcode); 
 }
 
 
-def build_stream(T, addr, nLds, W=1, stage_base=None, nStage=0):
+def build_stream(T, addr, nLds, W=1, stage_base=None, nStage=0, hoist=True):
     """-> dict(words, headers, granges={group: [(first header, end header)]*W}, gstats)
 
     A LONG instruction (more than 8 operands: the dot products of the factorisation and of the triangular solves,
@@ -243,6 +252,18 @@ def build_stream(T, addr, nLds, W=1, stage_base=None, nStage=0):
     lvl, nlev = group_levels(T)
     words, headers = [], []
     granges, gstats = {}, {}
+    # staging area = two alternating halves for terms computed one step ahead + the classic region, which must hold
+    # the longest staged instruction of the class
+    longest = 0
+    for i in range(1, T.n + 1):
+        if T.used[i] and ost[i] - ost[i - 1] > NSHORT:
+            op = int(types[i - 1])
+            tn = int(T.pars[T.parStart[i - 1]]) if op == I.I_sumprod else (_TERM[op][1] if op in _TERM else 1)
+            nt = (ost[i] - ost[i - 1] - _DOT_SKIP.get(op, 0)) // max(tn, 1)
+            if nt <= nStage:
+                longest = max(longest, nt)
+    half = (max(0, nStage - longest) // 2) // 8 * 8 if hoist else 0
+    cbase, cstage = (stage_base or 0) + 2 * half, nStage - 2 * half
     for g, members in enumerate(T.groups, 1):
         levels = {}
         for i in members.tolist():
@@ -276,7 +297,18 @@ def build_stream(T, addr, nLds, W=1, stage_base=None, nStage=0):
                 for k0 in range(0, len(items), LANES):
                     recs.append((cost(nn, items[k0]), op, kind, nn, aux, items[k0:k0 + LANES]))
             return recs
-        for l_ in sorted(levels):
+        # ---- classify every level; decide which levels run in ONE step ------------------------------------------
+        # Classic level with staged instructions: step A = its short records + ALL terms, step B = the folds (more
+        # rounds if the terms do not fit the staging area).  Hoisted level: the terms whose operands were complete
+        # two levels up ("early": 83 % of the products of mpc_quadcopter's factorisation) are computed one step
+        # AHEAD, next to the folds of the level before, into one of two alternating staging halves; the few "late"
+        # terms (an operand from the level just before: at most 2 per instruction, two-factor products) are computed
+        # by the folding lane itself, into its own staging slots, right before its chain.  Same operations, same
+        # order of additions -- one step (one barrier) per level instead of two.
+        Ls = sorted(levels)
+        info = []
+        for idx, l_ in enumerate(Ls):
+            prev = Ls[idx - 1] if idx else None
             short, long_, staged = {}, {}, []
             for i in levels[l_]:
                 op = int(types[i - 1])
@@ -317,36 +349,87 @@ def build_stream(T, addr, nLds, W=1, stage_base=None, nStage=0):
                 skip = _DOT_SKIP.get(op, 0)
                 nterm = (len(a) - skip) // tn
                 if nStage and tn <= NSHORT and nterm <= nStage and (len(a) - skip) % tn == 0:
-                    staged.append((op, fop, aux, d, a[:skip], top, tn, [a[skip + q * tn:skip + (q + 1) * tn] for q in range(nterm)]))
+                    tl = [a[skip + q * tn:skip + (q + 1) * tn] for q in range(nterm)]
+                    late = [prev is not None and any(T.group[j] == g and T.used[j] and lvl[j] >= prev
+                                                     for j in ops[skip + q * tn:skip + (q + 1) * tn]) for q in range(nterm)]
+                    staged.append(dict(op=op, fop=fop, aux=aux, d=d, heads=a[:skip], top=top, tn=tn, terms=tl, late=late))
                 else:
                     long_.setdefault((op, 0, aux), []).append((d, a))
-            recs = cut(short, K_SHORT, lambda nn, it: nn + 6)
             for key, items in long_.items():
                 long_[key] = sorted(items, key=lambda it: -len(it[1]))      # similar lengths share a record
-            recs += cut(long_, K_LONG, lambda nn, it: len(it[1]) + 8)
-            # staged long instructions: rounds that fit the staging area; the first round's terms share the step
-            # of the level's short records
-            staged.sort(key=lambda s_: -len(s_[7]))
-            k0 = 0
-            while True:
-                terms, folds, used = {}, {}, 0
-                while k0 < len(staged) and used + len(staged[k0][7]) <= nStage:
-                    op, fop, aux, d, heads, top, tn, tl = staged[k0]
-                    base = stage_base + used
-                    for q, tw in enumerate(tl):
-                        key = (I.I_sumprod, tn, tn) if top == "prod" else (top, tn, 0)
-                        terms.setdefault(key, []).append((base + q, tw))
-                    hw = [heads[q] if q < len(heads) else 2 for q in range(2)]
-                    folds.setdefault((fop, 0, aux), []).append((d, [len(tl), hw[0], hw[1], base]))
-                    used += len(tl)
-                    k0 += 1
-                emit(recs + cut(terms, K_SHORT, lambda nn, it: nn + 6))
-                recs = []
+            staged.sort(key=lambda s_: -len(s_["terms"]))
+            hoist = bool(staged) and idx > 0 and half >= 64
+            for s_ in staged:
+                nl = sum(s_["late"])
+                if nl and not (s_["top"] == "prod" and s_["tn"] == 2 and nl <= NLATE):
+                    hoist = False
+            if sum(len(s_["terms"]) for s_ in staged) > half:      # (late terms keep their slot in the row)
+                hoist = False
+            info.append(dict(short=short, long_=long_, staged=staged, hoist=hoist))
+
+        def fold_item(s_, base, inline):
+            hw = [s_["heads"][q] if q < len(s_["heads"]) else 2 for q in range(2)]
+            body = [len(s_["terms"]), hw[0], hw[1], base]
+            if inline:
+                lt = [q for q, x in enumerate(s_["late"]) if x]
+                body.append(len(lt))
+                for q in range(NLATE):
+                    body += [lt[q], s_["terms"][lt[q]][0], s_["terms"][lt[q]][1]] if q < len(lt) else [0, 2, 2]
+            return (s_["d"], body)
+
+        def term_key(s_):
+            return (I.I_sumprod, s_["tn"], s_["tn"]) if s_["top"] == "prod" else (s_["top"], s_["tn"], 0)
+        toggle = 0
+        ahead = []              # records of the NEXT level's early terms, to ride on this level's last step
+        for idx, lv in enumerate(info):
+            recs = cut(lv["short"], K_SHORT, lambda nn, it: nn + 6) + cut(lv["long_"], K_LONG, lambda nn, it: len(it[1]) + 8)
+            nxt = info[idx + 1] if idx + 1 < len(info) else None
+            ahead_next = []
+            if nxt is not None and nxt["hoist"]:
+                terms, used = {}, 0
+                hb = stage_base + toggle * half
+                toggle ^= 1
+                for s_ in nxt["staged"]:
+                    s_["base"] = hb + used
+                    for q, tw in enumerate(s_["terms"]):
+                        if not s_["late"][q]:
+                            terms.setdefault(term_key(s_), []).append((s_["base"] + q, tw))
+                    used += len(s_["terms"])       # the late terms keep their slot in the row: the folding lane fills it
+                if used > half:
+                    raise AssertionError("staging half overflow")
+                ahead_next = cut(terms, K_SHORT, lambda nn, it: nn + 6)
+            staged = lv["staged"]
+            if lv["hoist"]:
+                folds = {}
+                for s_ in staged:
+                    folds.setdefault((s_["fop"], 0, s_["aux"]), []).append(fold_item(s_, s_["base"], True))
                 for key, items in folds.items():
                     folds[key] = sorted(items, key=lambda it: -it[1][0])
-                emit(cut(folds, K_FOLD, lambda nn, it: it[1][0] // 2 + 8))
-                if k0 >= len(staged):
-                    break
+                emit(recs + cut(folds, K_FOLD, lambda nn, it: it[1][0] // 2 + 8) + ahead_next)
+            elif not staged:
+                emit(recs + ahead_next)
+            else:
+                # rounds that fit the classic staging region; the first round's terms share the step of the level's
+                # short records, the next level's early terms the step of the last folds
+                k0 = 0
+                while True:
+                    terms, folds, used = {}, {}, 0
+                    while k0 < len(staged) and used + len(staged[k0]["terms"]) <= cstage:
+                        s_ = staged[k0]
+                        base = cbase + used
+                        for q, tw in enumerate(s_["terms"]):
+                            terms.setdefault(term_key(s_), []).append((base + q, tw))
+                        folds.setdefault((s_["fop"], 0, s_["aux"]), []).append(fold_item(s_, base, False))
+                        used += len(s_["terms"])
+                        k0 += 1
+                    emit(recs + cut(terms, K_SHORT, lambda nn, it: nn + 6))
+                    recs = []
+                    for key, items in folds.items():
+                        folds[key] = sorted(items, key=lambda it: -it[1][0])
+                    last = k0 >= len(staged)
+                    emit(cut(folds, K_FOLD, lambda nn, it: it[1][0] // 2 + 8) + (ahead_next if last else []))
+                    if last:
+                        break
         rg = []
         for k in range(W):
             h0 = len(headers) // 8
@@ -384,11 +467,11 @@ def copy_records(words, headers, pairs, nLds, W=1):
     return rg
 
 
-def class_stream(T, classname, defines, W=1, lds_slots=20000):
+def class_stream(T, classname, defines, W=1, lds_slots=20000, hoist=True):
     """everything the device walk needs for one class"""
     sl = assign_slots(T, defines, lds_slots)
     addr, nLds = sl["addr"], sl["nLds"]
-    st = build_stream(T, addr, nLds, W, stage_base=sl["stage_base"], nStage=sl["nStage"])
+    st = build_stream(T, addr, nLds, W, stage_base=sl["stage_base"], nStage=sl["nStage"], hoist=hoist)
     words, headers = st["words"], st["headers"]
     rid, table = {}, []
     for g in sorted(st["granges"]):
@@ -431,7 +514,8 @@ def validate(words, headers, table, W, nLds, nAddr):
                     continue
                 if not (1 <= cnt <= LANES and cn % 8 == 0 and cnt <= cn):
                     raise AssertionError("bad record count")
-                na = 1 + n if kind == K_SHORT else (5 if kind == K_FOLD else 4 + n)
+                nlm = (flags >> F_NLATE_SHIFT) & 3 if kind == K_FOLD else 0
+                na = 1 + n if kind == K_SHORT else ((6 + 3 * NLATE if nlm else 5) if kind == K_FOLD else 4 + n)
                 if off < 0 or off + na * cn > len(words):
                     raise AssertionError("record body outside the code array")
                 body = np.asarray(words[off:off + na * cn]).reshape(na, cn)
@@ -441,6 +525,14 @@ def validate(words, headers, table, W, nLds, nAddr):
                             (body[4] + body[1]).max() > nLds:
                         raise AssertionError("bad fold record")
                     ops = body[2:4] >> 1
+                    if nlm:
+                        if nlm > NLATE or body[5].max() != nlm or body[5].min() < 0:
+                            raise AssertionError("bad late-term count")
+                        for q in range(NLATE):
+                            act = body[5][:cnt] > q
+                            if (body[6 + 3 * q][:cnt][act] >= body[1][:cnt][act]).any() or body[6 + 3 * q].min() < 0:
+                                raise AssertionError("late term outside the row")
+                        ops = np.concatenate([ops] + [body[7 + 3 * q:9 + 3 * q] >> 1 for q in range(NLATE)])
                 else:
                     ops = body[1:1 + n] >> 1 if kind == K_SHORT else body[2:4 + n] >> 1
                 if dst.min() < 0 or dst.max() >= nAddr or ops.min() < 0 or ops.max() >= nAddr:

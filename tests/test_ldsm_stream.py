@@ -99,6 +99,12 @@ class Machine:
                     res.append(_term(op, aux, [m[x >> 1] for x in ws], [x & 1 for x in ws]))
             elif kind == lsch.K_FOLD:
                 ln, h0, h1, base = rows(1), rows(2), rows(3), rows(4)
+                if (flags >> lsch.F_NLATE_SHIFT) & 3:            # late terms: computed by the folding lane itself
+                    nl = rows(5)
+                    for q in range(cnt):
+                        for t in range(nl[q]):
+                            pos, wa, wb = (rows(6 + 3 * t + j)[q] for j in range(3))
+                            m[base[q] + pos] = m[wa >> 1] * m[wb >> 1]
                 for q in range(cnt):
                     res.append(_fold(op, aux, [m[base[q] + k] for k in range(ln[q])], m[h0[q] >> 1], m[h1[q] >> 1]))
             else:
