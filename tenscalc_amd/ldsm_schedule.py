@@ -45,6 +45,7 @@ F_SUM = 3             # fold opcodes of K_FOLD records (the dot opcodes and I_su
 STAGE = 2048          # staging slots for the terms of long instructions
 F_GLOBAL_SRC, F_GLOBAL_DST, F_NEW_LEVEL = 1, 2, 4
 F_NLATE_SHIFT = 3      # flags bits 3-4 of a FOLD record: the largest late-term count among its lanes
+F_PADDED = 32          # FOLD record: every row is padded with -0.0 to a multiple of 8 terms (ordered sums)
 _DOT_SKIP = {I.I_minus_dot: 0, I.I_minus_dot_div: 1, I.I_plus_minus_dot: 1, I.I_plus_minus_dot_div: 2}
 _LONG_OPS = {I.I_sum, I.I_sumprod, I.I_plus_sqr, I.I_plus_abs, I.I_min, I.I_min0, I.I_max, I.I_max0,
              I.I_max_abs, I.I_clp, I.I_minus_dot, I.I_minus_dot_div, I.I_plus_minus_dot, I.I_plus_minus_dot_div}
@@ -113,7 +114,9 @@ def assign_slots(T, defines, lds_slots=20000, stage=STAGE):
     lds += 1
     zero = lds                                   # always 0.0: padding operand
     lds += 1
-    consts = [(zero, 0.0)]
+    negzero = lds                                # always -0.0: x + (-0.0) is x, pads the rows of ordered sums
+    lds += 1
+    consts = [(zero, 0.0), (negzero, -0.0)]
     for i in range(1, n + 1):
         if T.isload[i - 1] and (read_any[i] or direct[i]):
             where[i] = lds
@@ -179,7 +182,7 @@ def assign_slots(T, defines, lds_slots=20000, stage=STAGE):
     for i, q in gslot.items():
         where[i] = nLds + q
     return dict(addr=where, nLds=nLds, nGlob=nExt + nCold, nExt=nExt, consts=consts, inputs=inputs, dummy=dummy,
-                zero=zero, stage_base=stage_base, nStage=int(stage), nLocal=nLocal, nHot=nHot, nCold=nCold, hot_blocks=len(hot), cold_blocks=len(cold),
+                zero=zero, negzero=negzero, stage_base=stage_base, nStage=int(stage), nLocal=nLocal, nHot=nHot, nCold=nCold, hot_blocks=len(hot), cold_blocks=len(cold),
                 lowering=L, levels=lvl, nlev=nlev)
 
 
@@ -207,6 +210,8 @@ def _rec(words, headers, op, kind, n, aux, items, nLds, new_level):
         for j in range(rows):
             words += pad([a[j] for _, a in items], items[-1][1][j])
         nn = -(-max(a[0] for _, a in items) // 8) * 8
+        if op in _PADDED_FOPS:
+            flags |= F_PADDED
         flags &= ~F_GLOBAL_SRC
         if any((a[j] >> 1) >= nLds for _, a in items for j in (1, 2)):
             flags |= F_GLOBAL_SRC
@@ -227,6 +232,9 @@ def _rec(words, headers, op, kind, n, aux, items, nLds, new_level):
     headers += [op | (kind << 8), nn, aux, cnt, off, flags, cn, 0]
 
 
+# folds whose rows are padded with -0.0 to a multiple of 8 terms: the chain of an ordered sum then needs neither a
+# select nor a clamped address per term (I_sumprod keeps the select: its statement split would run past the row)
+_PADDED_FOPS = (I.I_minus_dot, I.I_minus_dot_div, I.I_plus_minus_dot, I.I_plus_minus_dot_div, F_SUM)
 _TERM = {  # long instruction -> (term opcode, operands per term, fold opcode); terms are evaluated in parallel, one per
     # lane, into consecutive staging slots; ONE lane then folds them strictly left to right
     I.I_minus_dot: ("prod", 2, I.I_minus_dot), I.I_minus_dot_div: ("prod", 2, I.I_minus_dot_div),
@@ -237,7 +245,7 @@ _TERM = {  # long instruction -> (term opcode, operands per term, fold opcode); 
 }
 
 
-def build_stream(T, addr, nLds, W=1, stage_base=None, nStage=0, hoist=True):
+def build_stream(T, addr, nLds, W=1, stage_base=None, nStage=0, hoist=True, negzero=None):
     """-> dict(words, headers, granges={group: [(first header, end header)]*W}, gstats)
 
     A LONG instruction (more than 8 operands: the dot products of the factorisation and of the triangular solves,
@@ -252,6 +260,10 @@ def build_stream(T, addr, nLds, W=1, stage_base=None, nStage=0, hoist=True):
     lvl, nlev = group_levels(T)
     words, headers = [], []
     granges, gstats = {}, {}
+
+    def rowlen(s_):
+        n_ = len(s_["terms"])
+        return -(-n_ // 8) * 8 if s_["fop"] in _PADDED_FOPS else n_
     # staging area = two alternating halves for terms computed one step ahead + the classic region, which must hold
     # the longest staged instruction of the class
     longest = 0
@@ -261,7 +273,7 @@ def build_stream(T, addr, nLds, W=1, stage_base=None, nStage=0, hoist=True):
             tn = int(T.pars[T.parStart[i - 1]]) if op == I.I_sumprod else (_TERM[op][1] if op in _TERM else 1)
             nt = (ost[i] - ost[i - 1] - _DOT_SKIP.get(op, 0)) // max(tn, 1)
             if nt <= nStage:
-                longest = max(longest, nt)
+                longest = max(longest, -(-nt // 8) * 8)
     half = (max(0, nStage - longest) // 2) // 8 * 8 if hoist else 0
     cbase, cstage = (stage_base or 0) + 2 * half, nStage - 2 * half
     for g, members in enumerate(T.groups, 1):
@@ -348,7 +360,7 @@ def build_stream(T, addr, nLds, W=1, stage_base=None, nStage=0, hoist=True):
                     top, tn, fop = _TERM[op]
                 skip = _DOT_SKIP.get(op, 0)
                 nterm = (len(a) - skip) // tn
-                if nStage and tn <= NSHORT and nterm <= nStage and (len(a) - skip) % tn == 0:
+                if nStage and tn <= NSHORT and -(-nterm // 8) * 8 <= cstage and (len(a) - skip) % tn == 0:
                     tl = [a[skip + q * tn:skip + (q + 1) * tn] for q in range(nterm)]
                     late = [prev is not None and any(T.group[j] == g and T.used[j] and lvl[j] >= prev
                                                      for j in ops[skip + q * tn:skip + (q + 1) * tn]) for q in range(nterm)]
@@ -363,7 +375,7 @@ def build_stream(T, addr, nLds, W=1, stage_base=None, nStage=0, hoist=True):
                 nl = sum(s_["late"])
                 if nl and not (s_["top"] == "prod" and s_["tn"] == 2 and nl <= NLATE):
                     hoist = False
-            if sum(len(s_["terms"]) for s_ in staged) > half:      # (late terms keep their slot in the row)
+            if sum(rowlen(s_) for s_ in staged) > half:            # (late terms keep their slot in the row)
                 hoist = False
             info.append(dict(short=short, long_=long_, staged=staged, hoist=hoist))
 
@@ -379,6 +391,12 @@ def build_stream(T, addr, nLds, W=1, stage_base=None, nStage=0, hoist=True):
 
         def term_key(s_):
             return (I.I_sumprod, s_["tn"], s_["tn"]) if s_["top"] == "prod" else (s_["top"], s_["tn"], 0)
+
+        def add_pads(terms, s_, base):
+            """-0.0 into the slots between the end of the row and the next multiple of 8 (ordered sums only)"""
+            if s_["fop"] in _PADDED_FOPS:
+                for q in range(len(s_["terms"]), rowlen(s_)):
+                    terms.setdefault((OP_COPY, 1, 0), []).append((base + q, [negzero * 2]))
         toggle = 0
         ahead = []              # records of the NEXT level's early terms, to ride on this level's last step
         for idx, lv in enumerate(info):
@@ -394,7 +412,8 @@ def build_stream(T, addr, nLds, W=1, stage_base=None, nStage=0, hoist=True):
                     for q, tw in enumerate(s_["terms"]):
                         if not s_["late"][q]:
                             terms.setdefault(term_key(s_), []).append((s_["base"] + q, tw))
-                    used += len(s_["terms"])       # the late terms keep their slot in the row: the folding lane fills it
+                    add_pads(terms, s_, s_["base"])
+                    used += rowlen(s_)             # the late terms keep their slot in the row: the folding lane fills it
                 if used > half:
                     raise AssertionError("staging half overflow")
                 ahead_next = cut(terms, K_SHORT, lambda nn, it: nn + 6)
@@ -414,13 +433,14 @@ def build_stream(T, addr, nLds, W=1, stage_base=None, nStage=0, hoist=True):
                 k0 = 0
                 while True:
                     terms, folds, used = {}, {}, 0
-                    while k0 < len(staged) and used + len(staged[k0]["terms"]) <= cstage:
+                    while k0 < len(staged) and used + rowlen(staged[k0]) <= cstage:
                         s_ = staged[k0]
                         base = cbase + used
                         for q, tw in enumerate(s_["terms"]):
                             terms.setdefault(term_key(s_), []).append((base + q, tw))
+                        add_pads(terms, s_, base)
                         folds.setdefault((s_["fop"], 0, s_["aux"]), []).append(fold_item(s_, base, False))
-                        used += len(s_["terms"])
+                        used += rowlen(s_)
                         k0 += 1
                     emit(recs + cut(terms, K_SHORT, lambda nn, it: nn + 6))
                     recs = []
@@ -471,7 +491,8 @@ def class_stream(T, classname, defines, W=1, lds_slots=20000, hoist=True):
     """everything the device walk needs for one class"""
     sl = assign_slots(T, defines, lds_slots)
     addr, nLds = sl["addr"], sl["nLds"]
-    st = build_stream(T, addr, nLds, W, stage_base=sl["stage_base"], nStage=sl["nStage"], hoist=hoist)
+    st = build_stream(T, addr, nLds, W, stage_base=sl["stage_base"], nStage=sl["nStage"], hoist=hoist,
+                      negzero=sl["negzero"])
     words, headers = st["words"], st["headers"]
     rid, table = {}, []
     for g in sorted(st["granges"]):
@@ -521,8 +542,9 @@ def validate(words, headers, table, W, nLds, nAddr):
                 body = np.asarray(words[off:off + na * cn]).reshape(na, cn)
                 dst = body[0]
                 if kind == K_FOLD:
+                    rl = (body[1] + 7) // 8 * 8 if flags & F_PADDED else body[1]
                     if n % 8 or body[1].max() > n or body[1][:cnt].min() < 1 or body[4].min() < 0 or \
-                            (body[4] + body[1]).max() > nLds:
+                            (body[4] + rl).max() > nLds:
                         raise AssertionError("bad fold record")
                     ops = body[2:4] >> 1
                     if nlm:

@@ -106,7 +106,9 @@ class Machine:
                             pos, wa, wb = (rows(6 + 3 * t + j)[q] for j in range(3))
                             m[base[q] + pos] = m[wa >> 1] * m[wb >> 1]
                 for q in range(cnt):
-                    res.append(_fold(op, aux, [m[base[q] + k] for k in range(ln[q])], m[h0[q] >> 1], m[h1[q] >> 1]))
+                    # a padded row (ordered sums) is added up to the next multiple of 8: the pads must hold -0.0
+                    nrow = -(-ln[q] // 8) * 8 if flags & lsch.F_PADDED else ln[q]
+                    res.append(_fold(op, aux, [m[base[q] + k] for k in range(nrow)], m[h0[q] >> 1], m[h1[q] >> 1]))
             else:
                 ln = rows(1)
                 for q in range(cnt):
