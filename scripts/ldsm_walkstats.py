@@ -37,6 +37,7 @@ print(f"{prob} {variant}: kernel {tm*1e3:.1f} ms, instance 0: {it[0]} iterations
 print(f"walk cycles (wave 0): total {tot}  = {tot/max(it[0],1):.0f} per iteration")
 for nm, v in zip(["wait for body words", "execute records", "barriers", "rest of the walk"], w[:4]):
     print(f"  {nm:22s} {v:12d}  {100*v/tot:5.1f}%")
+print(f"  of the rest: issuing the body-word loads of the record 4 ahead {w[7]} = {w[7]/max(w[4]+w[5],1):.0f} per step")
 print(f"records {w[4]} ({w[1]/max(w[4],1):.0f} cycles each), barriers {w[5]} ({w[2]/max(w[5],1):.0f} each), "
       f"calls {w[6]} ({w[3]/max(w[6],1):.0f} rest each); wait per step {w[0]/max(w[4]+w[5],1):.0f}")
 names_ = ["long"] + ["short n=%d" % n for n in range(1, 9)] + ["fold <=%d" % (8 * (q + 1)) for q in range(8)] + ["fold >64"]

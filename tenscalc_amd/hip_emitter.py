@@ -1502,7 +1502,9 @@ def emit_class_ldsm(spec, waves=4, stats=False, lds_slots=20000):
         w.append(",".join(str(int(x)) for x in harr[k0:k0 + 32]) + ",\n")
     w.append("};\nstatic __device__ const int tc_rng[] __attribute__((aligned(64))) = {"
              + ", ".join(str(int(x)) for x in cs["table"]) + ", 0, 0};\n"
-             "static __device__ const double tc_consts[] = {" + ", ".join(_lit(v) for _, v in cs["consts"]) + "};\n"
+             "static __device__ const double tc_consts[] = {" + ", ".join(
+                 ("__builtin_inf()" if v > 0 else "-__builtin_inf()") if v in (float("inf"), float("-inf")) else _lit(v)
+                 for _, v in cs["consts"]) + "};\n"
              "static __device__ const int tc_const_addr[] = {" + ", ".join(str(int(a)) for a, _ in cs["consts"]) + "};\n"
              f"#define TC_NCONST {len(cs['consts'])}\n"
              '#include "tc_ldsm.hip.inc"\n\n')

@@ -116,7 +116,9 @@ def assign_slots(T, defines, lds_slots=20000, stage=STAGE):
     lds += 1
     negzero = lds                                # always -0.0: x + (-0.0) is x, pads the rows of ordered sums
     lds += 1
-    consts = [(zero, 0.0), (negzero, -0.0)]
+    posinf, neginf = lds, lds + 1                # pads of the rows of minima / maxima
+    lds += 2
+    consts = [(zero, 0.0), (negzero, -0.0), (posinf, float("inf")), (neginf, float("-inf"))]
     for i in range(1, n + 1):
         if T.isload[i - 1] and (read_any[i] or direct[i]):
             where[i] = lds
@@ -182,7 +184,7 @@ def assign_slots(T, defines, lds_slots=20000, stage=STAGE):
     for i, q in gslot.items():
         where[i] = nLds + q
     return dict(addr=where, nLds=nLds, nGlob=nExt + nCold, nExt=nExt, consts=consts, inputs=inputs, dummy=dummy,
-                zero=zero, negzero=negzero, stage_base=stage_base, nStage=int(stage), nLocal=nLocal, nHot=nHot, nCold=nCold, hot_blocks=len(hot), cold_blocks=len(cold),
+                zero=zero, negzero=negzero, posinf=posinf, neginf=neginf, stage_base=stage_base, nStage=int(stage), nLocal=nLocal, nHot=nHot, nCold=nCold, hot_blocks=len(hot), cold_blocks=len(cold),
                 lowering=L, levels=lvl, nlev=nlev)
 
 
@@ -232,9 +234,10 @@ def _rec(words, headers, op, kind, n, aux, items, nLds, new_level):
     headers += [op | (kind << 8), nn, aux, cnt, off, flags, cn, 0]
 
 
-# folds whose rows are padded with -0.0 to a multiple of 8 terms: the chain of an ordered sum then needs neither a
-# select nor a clamped address per term (I_sumprod keeps the select: its statement split would run past the row)
-_PADDED_FOPS = (I.I_minus_dot, I.I_minus_dot_div, I.I_plus_minus_dot, I.I_plus_minus_dot_div, F_SUM)
+# the rows of every fold are padded to a multiple of 8 terms with the operation's identity (index into `pads`:
+# 0 = -0.0, 1 = +inf, 2 = -inf): the chain then needs neither a select nor a clamped address per term
+_PADDED_FOPS = {I.I_minus_dot: 0, I.I_minus_dot_div: 0, I.I_plus_minus_dot: 0, I.I_plus_minus_dot_div: 0, F_SUM: 0,
+                I.I_sumprod: 0, I.I_min: 1, I.I_min0: 1, I.I_clp: 1, I.I_max: 2, I.I_max0: 2}
 _TERM = {  # long instruction -> (term opcode, operands per term, fold opcode); terms are evaluated in parallel, one per
     # lane, into consecutive staging slots; ONE lane then folds them strictly left to right
     I.I_minus_dot: ("prod", 2, I.I_minus_dot), I.I_minus_dot_div: ("prod", 2, I.I_minus_dot_div),
@@ -245,7 +248,7 @@ _TERM = {  # long instruction -> (term opcode, operands per term, fold opcode); 
 }
 
 
-def build_stream(T, addr, nLds, W=1, stage_base=None, nStage=0, hoist=True, negzero=None):
+def build_stream(T, addr, nLds, W=1, stage_base=None, nStage=0, hoist=True, pads=None):
     """-> dict(words, headers, granges={group: [(first header, end header)]*W}, gstats)
 
     A LONG instruction (more than 8 operands: the dot products of the factorisation and of the triangular solves,
@@ -393,10 +396,11 @@ def build_stream(T, addr, nLds, W=1, stage_base=None, nStage=0, hoist=True, negz
             return (I.I_sumprod, s_["tn"], s_["tn"]) if s_["top"] == "prod" else (s_["top"], s_["tn"], 0)
 
         def add_pads(terms, s_, base):
-            """-0.0 into the slots between the end of the row and the next multiple of 8 (ordered sums only)"""
+            """the operation's identity (-0.0 for sums, +inf for minima, -inf for maxima) into the slots between the
+            end of the row and the next multiple of 8"""
             if s_["fop"] in _PADDED_FOPS:
                 for q in range(len(s_["terms"]), rowlen(s_)):
-                    terms.setdefault((OP_COPY, 1, 0), []).append((base + q, [negzero * 2]))
+                    terms.setdefault((OP_COPY, 1, 0), []).append((base + q, [pads[_PADDED_FOPS[s_["fop"]]] * 2]))
         toggle = 0
         ahead = []              # records of the NEXT level's early terms, to ride on this level's last step
         for idx, lv in enumerate(info):
@@ -492,7 +496,7 @@ def class_stream(T, classname, defines, W=1, lds_slots=20000, hoist=True):
     sl = assign_slots(T, defines, lds_slots)
     addr, nLds = sl["addr"], sl["nLds"]
     st = build_stream(T, addr, nLds, W, stage_base=sl["stage_base"], nStage=sl["nStage"], hoist=hoist,
-                      negzero=sl["negzero"])
+                      pads=(sl["negzero"], sl["posinf"], sl["neginf"]))
     words, headers = st["words"], st["headers"]
     rid, table = {}, []
     for g in sorted(st["granges"]):
