@@ -29,7 +29,7 @@ for n in names:
     obj.set(n, np.stack([np.asarray(d[n], dtype=float).reshape(-1, order="F") for d in data]))
 st, it, tm = obj.solve(**SOLVE_ARGS)
 lib = ctypes.CDLL(so)
-out = (ctypes.c_ulonglong * 48)()
+out = (ctypes.c_ulonglong * 56)()
 rc = lib.tc_ldsm_walkstats(out)
 w = [int(x) for x in out]
 tot = sum(w[:4])
@@ -38,6 +38,7 @@ print(f"walk cycles (wave 0): total {tot}  = {tot/max(it[0],1):.0f} per iteratio
 for nm, v in zip(["wait for body words", "execute records", "barriers", "rest of the walk"], w[:4]):
     print(f"  {nm:22s} {v:12d}  {100*v/tot:5.1f}%")
 print(f"  of the rest: issuing the body-word loads of the record 4 ahead {w[7]} = {w[7]/max(w[4]+w[5],1):.0f} per step")
+print(f"  per call: entry barrier {w[48]/max(w[6],1):.0f}, record range + first headers {w[49]/max(w[6],1):.0f}")
 print(f"records {w[4]} ({w[1]/max(w[4],1):.0f} cycles each), barriers {w[5]} ({w[2]/max(w[5],1):.0f} each), "
       f"calls {w[6]} ({w[3]/max(w[6],1):.0f} rest each); wait per step {w[0]/max(w[4]+w[5],1):.0f}")
 names_ = ["long"] + ["short n=%d" % n for n in range(1, 9)] + ["fold <=%d" % (8 * (q + 1)) for q in range(8)] + ["fold >64"]
