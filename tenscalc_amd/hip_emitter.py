@@ -1484,7 +1484,7 @@ def emit_class_ldsm(spec, waves=4, stats=False, lds_slots=20000):
              "static __device__ __forceinline__ double tc_max(double a, double x) { return (a < x) ? x : a; }\n"
              "static __device__ __forceinline__ double tc_clp(double a, double x, double dx) {\n"
              "  if (dx < 0) { const double t = -x / dx; if (a > t) a = t; }\n  return a;\n}\n\n")
-    arr = lsch.as_array(cs["words"] + [0] * 1024)    # the body prefetch reads up to 12 rows of 64 past a record
+    arr = lsch.as_array(cs["words"] + [0] * 1024)    # the body prefetch reads up to 16 rows of 64 past a record
     w.append(f"// the tape as data: {arr.size} body words, {len(cs['headers']) // 8} record headers\n"
              "static __device__ const int tc_code[] __attribute__((aligned(64))) = {\n")
     for k0 in range(0, arr.size, 32):

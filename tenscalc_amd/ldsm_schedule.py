@@ -38,9 +38,11 @@ from . import instructions as I
 LANES = 64
 NSHORT = 8            # operands of a SHORT record
 K_SHORT, K_LONG, K_BARRIER, K_FOLD = 1, 0, 2, 3
-NLATE = 2              # late terms a FOLD record can compute itself (body rows 5..11: count, 2 x (position, 2 operands))
+NLATE = 2              # late terms a FOLD record can compute itself (body rows 5..13: count, 2 x (position, a, b, c):
+                       # the term is a * (b * c), c = the slot holding 1.0 for a plain product)
 OP_COPY = 60
 OP_CLPTERM = 61       # (b < 0) ? -a/b : DBL_MAX  -- one term of I_clp
+OP_PROD3 = 62         # a * (b * c): a term of a dot one of whose factors is itself a product of the level before
 F_SUM = 3             # fold opcodes of K_FOLD records (the dot opcodes and I_sumprod keep their own number)
 STAGE = 2048          # staging slots for the terms of long instructions
 F_GLOBAL_SRC, F_GLOBAL_DST, F_NEW_LEVEL = 1, 2, 4
@@ -64,6 +66,64 @@ def group_levels(T):
             l_ = 0
             for j in opl[ost[i - 1]:ost[i]]:
                 if grp[j] == g and lvl[j] + 1 > l_:
+                    l_ = lvl[j] + 1
+            lvl[i] = l_
+            if l_ > mx:
+                mx = l_
+        nlev[g] = mx + 1
+    return lvl, nlev
+
+
+_DOTS = (I.I_minus_dot, I.I_minus_dot_div, I.I_plus_minus_dot, I.I_plus_minus_dot_div)
+
+
+def _is_product(T, opl, ost, j):
+    """instruction j is v = p * q (I_sumprod, one term of two factors)"""
+    return int(T.types[j - 1]) == I.I_sumprod and ost[j] - ost[j - 1] == 2 and int(T.pars[T.parStart[j - 1]]) == 2
+
+
+def _nested_factor(T, opl, ost, g, ids):
+    """which factor (0 / 1) of the term ids=(a, b) of a dot may be expanded into its own two factors: the second if
+    it is a plain product of group g, else the first; never both (stream_levels and build_stream must agree)"""
+    for k in (1, 0):
+        j = ids[k]
+        if T.group[j] == g and T.used[j] and _is_product(T, opl, ost, j):
+            return k
+    return None
+
+
+def stream_levels(T, nested=True):
+    """Levels for the record stream.  As group_levels, except that a staged dot product (more than NSHORT operands)
+    does not wait for a factor that is itself a plain product v = p*q of its group: the term a*v can be evaluated
+    as the nested product a*(p*q) -- the same two roundings in the same order -- from operands that are one level
+    older.  In the symbolic LDL (sparsity_ldl.m:161-222) v_i = L(c,i)*D(i) is such a product: D(c) and L(r,c) move
+    up a level, two levels per column instead of three."""
+    opl, ost = T.ops.tolist(), T.opStart.tolist()
+    grp = T.group.tolist()
+    lvl = [0] * (T.n + 1)
+    nlev = [0] * (T.nGroups + 1)
+    for g, members in enumerate(T.groups, 1):
+        mx = -1
+        for i in members.tolist():
+            ops = opl[ost[i - 1]:ost[i]]
+            op = int(T.types[i - 1])
+            dot = nested and op in _DOTS and len(ops) > NSHORT
+            skip = _DOT_SKIP.get(op, 0) if dot else 0
+            l_ = 0
+            expand = set()
+            if dot:
+                for q in range(skip, len(ops) - 1, 2):
+                    k = _nested_factor(T, opl, ost, g, ops[q:q + 2])
+                    if k is not None:
+                        expand.add(q + k)
+            for q, j in enumerate(ops):
+                if grp[j] != g:
+                    continue
+                if q in expand:
+                    for jj in opl[ost[j - 1]:ost[j]]:
+                        if grp[jj] == g and lvl[jj] + 1 > l_:
+                            l_ = lvl[jj] + 1
+                elif lvl[j] + 1 > l_:
                     l_ = lvl[j] + 1
             lvl[i] = l_
             if l_ > mx:
@@ -117,8 +177,9 @@ def assign_slots(T, defines, lds_slots=20000, stage=STAGE):
     negzero = lds                                # always -0.0: x + (-0.0) is x, pads the rows of ordered sums
     lds += 1
     posinf, neginf = lds, lds + 1                # pads of the rows of minima / maxima
-    lds += 2
-    consts = [(zero, 0.0), (negzero, -0.0), (posinf, float("inf")), (neginf, float("-inf"))]
+    one = lds + 2                                # third factor of a late term that is a plain product
+    lds += 3
+    consts = [(zero, 0.0), (negzero, -0.0), (posinf, float("inf")), (neginf, float("-inf")), (one, 1.0)]
     for i in range(1, n + 1):
         if T.isload[i - 1] and (read_any[i] or direct[i]):
             where[i] = lds
@@ -184,13 +245,19 @@ def assign_slots(T, defines, lds_slots=20000, stage=STAGE):
     for i, q in gslot.items():
         where[i] = nLds + q
     return dict(addr=where, nLds=nLds, nGlob=nExt + nCold, nExt=nExt, consts=consts, inputs=inputs, dummy=dummy,
-                zero=zero, negzero=negzero, posinf=posinf, neginf=neginf, stage_base=stage_base, nStage=int(stage), nLocal=nLocal, nHot=nHot, nCold=nCold, hot_blocks=len(hot), cold_blocks=len(cold),
+                zero=zero, negzero=negzero, posinf=posinf, neginf=neginf, one=one, stage_base=stage_base, nStage=int(stage), nLocal=nLocal, nHot=nHot, nCold=nCold, hot_blocks=len(hot), cold_blocks=len(cold),
                 lowering=L, levels=lvl, nlev=nlev)
 
 
 # ---------------------------------------------------------------------------------------------------------------
 def _rec(words, headers, op, kind, n, aux, items, nLds, new_level):
-    """one record: items = [(dest addr, [operand words])] (<= 64, same shape for SHORT)"""
+    """one record: items = [(dest addr, [operand words])] (<= 64, same shape for SHORT).
+
+    Body layout.  SHORT and FOLD: array of structures -- lane q's words are contiguous at off + q*S, S = the row
+    count rounded up to a multiple of 4, so that a lane fetches its body with one to three 16-byte loads
+    (SHORT: dest, operands; FOLD: dest, len, head0, head1, base and, with late terms, nlate | pos0 << 2 | pos1 << 17,
+    a0, b0, c0, a1, b1, c1).  LONG: structure of arrays, rows of cn words (dest, len, head0, head1, then the operand
+    lists, which a lane walks chunk by chunk)."""
     cnt = len(items)
     cn = -(-cnt // 8) * 8
     flags = F_NEW_LEVEL if new_level else 0
@@ -199,18 +266,31 @@ def _rec(words, headers, op, kind, n, aux, items, nLds, new_level):
     if any(d >= nLds for d, _ in items):
         flags |= F_GLOBAL_DST
     off = len(words)
+    if off % 4:
+        raise AssertionError("record bodies start on 16-byte boundaries")
     pad = lambda v, fill: list(v) + [fill] * (cn - len(v))        # noqa: E731
-    words += pad([d for d, _ in items], items[-1][0])
+
+    def aos(rows):
+        S = -(-len(rows[0]) // 4) * 4
+        for q in range(cn):
+            r = rows[min(q, cnt - 1)]
+            words.extend(list(r) + [0] * (S - len(r)))
     if kind == K_SHORT:
-        for j in range(n):
-            words += pad([a[j] for _, a in items], items[-1][1][j])
+        aos([[d] + list(a[:n]) for d, a in items])
         nn = n
-    elif kind == K_FOLD:      # items: (dest, [len, head0, head1, base (, nlate, NLATE x (position, operand, operand))])
+    elif kind == K_FOLD:      # items: (dest, [len, head0, head1, base (, nlate, NLATE x (position, a, b, c))])
         rows = len(items[0][1])
         if any(len(a) != rows for _, a in items):
             raise AssertionError("fold record: mixed body shapes")
-        for j in range(rows):
-            words += pad([a[j] for _, a in items], items[-1][1][j])
+        if rows > 4 and max(a[4] for _, a in items) == 0:       # no lane of this record has a late term
+            items = [(d, a[:4]) for d, a in items]
+            rows = 4
+        if rows > 4:
+            if NLATE != 2 or any(a[5] >= 1 << 15 or a[9] >= 1 << 14 for _, a in items):
+                raise AssertionError("late-term positions do not fit the packed word")
+            aos([[d] + list(a[:4]) + [a[4] | a[5] << 2 | a[9] << 17, a[6], a[7], a[8], a[10], a[11], a[12]] for d, a in items])
+        else:
+            aos([[d] + list(a) for d, a in items])
         nn = -(-max(a[0] for _, a in items) // 8) * 8
         if op in _PADDED_FOPS:
             flags |= F_PADDED
@@ -219,9 +299,10 @@ def _rec(words, headers, op, kind, n, aux, items, nLds, new_level):
             flags |= F_GLOBAL_SRC
         if rows > 4:
             flags |= max(a[4] for _, a in items) << F_NLATE_SHIFT
-            if any((a[j] >> 1) >= nLds for _, a in items for q in range(NLATE) for j in (6 + 3 * q, 7 + 3 * q)):
+            if any((a[j] >> 1) >= nLds for _, a in items for q in range(NLATE) for j in (6 + 4 * q, 7 + 4 * q, 8 + 4 * q)):
                 flags |= F_GLOBAL_SRC
     else:
+        words += pad([d for d, _ in items], items[-1][0])
         skip = _DOT_SKIP.get(op, 0)
         lens = [len(a) - skip for _, a in items]
         mx = -(-max(lens) // 8) * 8
@@ -232,6 +313,28 @@ def _rec(words, headers, op, kind, n, aux, items, nLds, new_level):
             words += pad([a[skip + k] if skip + k < len(a) else 2 for _, a in items], 2)     # 2 = the zero slot (addr 1)
         nn = mx
     headers += [op | (kind << 8), nn, aux, cnt, off, flags, cn, 0]
+
+
+def record_body(words, hdr):
+    """logical body rows of a record, [row][lane < cnt]: SHORT dest, operands; FOLD dest, len, head0, head1, base
+    (, nlate, pos0, a0, b0, c0, pos1, a1, b1, c1); LONG dest, len, head0, head1, operand words"""
+    w0, n, aux, cnt, off, flags, cn, _ = (int(x) for x in hdr)
+    kind = w0 >> 8
+    if kind == K_LONG:
+        na = 4 + n
+        if off + na * cn > len(words):
+            raise AssertionError("record body outside the code array")
+        return np.asarray(words[off:off + na * cn], dtype=np.int64).reshape(na, cn)[:, :cnt]
+    nlm = (flags >> F_NLATE_SHIFT) & 3 if kind == K_FOLD else 0
+    na = 1 + n if kind == K_SHORT else (12 if nlm else 5)
+    S = -(-na // 4) * 4
+    if off + S * cn > len(words):
+        raise AssertionError("record body outside the code array")
+    b = np.asarray(words[off:off + S * cn], dtype=np.int64).reshape(cn, S).T[:na, :cnt]
+    if nlm:
+        pk = b[5]
+        b = np.vstack([b[:5], pk & 3, (pk >> 2) & 0x7fff, b[6:9], pk >> 17, b[9:12]])
+    return b
 
 
 # the rows of every fold are padded to a multiple of 8 terms with the operation's identity (index into `pads`:
@@ -248,7 +351,7 @@ _TERM = {  # long instruction -> (term opcode, operands per term, fold opcode); 
 }
 
 
-def build_stream(T, addr, nLds, W=1, stage_base=None, nStage=0, hoist=True, pads=None):
+def build_stream(T, addr, nLds, W=1, stage_base=None, nStage=0, hoist=True, pads=None, one=None, nested=True):
     """-> dict(words, headers, granges={group: [(first header, end header)]*W}, gstats)
 
     A LONG instruction (more than 8 operands: the dot products of the factorisation and of the triangular solves,
@@ -260,7 +363,8 @@ def build_stream(T, addr, nLds, W=1, stage_base=None, nStage=0, hoist=True, pads
     reference's left-to-right chain, so values do not change."""
     opl, ost = T.ops.tolist(), T.opStart.tolist()
     types = T.types
-    lvl, nlev = group_levels(T)
+    nested = bool(nested and hoist and one is not None)
+    lvl, nlev = stream_levels(T, nested)
     words, headers = [], []
     granges, gstats = {}, {}
 
@@ -364,9 +468,26 @@ def build_stream(T, addr, nLds, W=1, stage_base=None, nStage=0, hoist=True, pads
                 skip = _DOT_SKIP.get(op, 0)
                 nterm = (len(a) - skip) // tn
                 if nStage and tn <= NSHORT and -(-nterm // 8) * 8 <= cstage and (len(a) - skip) % tn == 0:
-                    tl = [a[skip + q * tn:skip + (q + 1) * tn] for q in range(nterm)]
-                    late = [prev is not None and any(T.group[j] == g and T.used[j] and lvl[j] >= prev
-                                                     for j in ops[skip + q * tn:skip + (q + 1) * tn]) for q in range(nterm)]
+                    tl, late = [], []
+                    for q in range(nterm):
+                        ids = list(ops[skip + q * tn:skip + (q + 1) * tn])
+                        tw = list(a[skip + q * tn:skip + (q + 1) * tn])
+                        if nested and op in _DOTS:
+                            # a factor that is a plain product of the level before (or later: stream_levels did not
+                            # wait for it) is expanded: a*v -> a*(p*q), the same two roundings in the same order
+                            k = _nested_factor(T, opl, ost, g, ids)
+                            if k is not None and prev is not None and lvl[ids[k]] >= prev:
+                                pj = opl[ost[ids[k] - 1]:ost[ids[k]]]
+                                ids = [ids[1 - k]] + list(pj)
+                                tw = [tw[1 - k]] + [int(addr[j]) * 2 for j in pj]
+                                if min(tw) < 0:
+                                    raise AssertionError("nested product: operand without storage")
+                            elif k is not None and prev is None and lvl[ids[k]] >= l_:
+                                raise AssertionError("nested product at the first level of a group")
+                        tl.append(tw)
+                        late.append(prev is not None and any(T.group[j] == g and T.used[j] and lvl[j] >= prev for j in ids))
+                        if any(T.group[j] == g and T.used[j] and lvl[j] >= l_ for j in ids):
+                            raise AssertionError(f"instruction {i}: a term needs a value of its own level")
                     staged.append(dict(op=op, fop=fop, aux=aux, d=d, heads=a[:skip], top=top, tn=tn, terms=tl, late=late))
                 else:
                     long_.setdefault((op, 0, aux), []).append((d, a))
@@ -388,12 +509,15 @@ def build_stream(T, addr, nLds, W=1, stage_base=None, nStage=0, hoist=True, pads
             if inline:
                 lt = [q for q, x in enumerate(s_["late"]) if x]
                 body.append(len(lt))
-                for q in range(NLATE):
-                    body += [lt[q], s_["terms"][lt[q]][0], s_["terms"][lt[q]][1]] if q < len(lt) else [0, 2, 2]
+                for q in range(NLATE):      # position, a, b, c: the term is a * (b * c)
+                    tw = s_["terms"][lt[q]] if q < len(lt) else [2, 2]
+                    body += [lt[q] if q < len(lt) else 0, tw[0], tw[1], tw[2] if len(tw) == 3 else one * 2]
             return (s_["d"], body)
 
-        def term_key(s_):
-            return (I.I_sumprod, s_["tn"], s_["tn"]) if s_["top"] == "prod" else (s_["top"], s_["tn"], 0)
+        def term_key(s_, tw):
+            if s_["top"] == "prod":
+                return (OP_PROD3, 3, 0) if len(tw) == 3 and s_["tn"] == 2 else (I.I_sumprod, s_["tn"], s_["tn"])
+            return (s_["top"], s_["tn"], 0)
 
         def add_pads(terms, s_, base):
             """the operation's identity (-0.0 for sums, +inf for minima, -inf for maxima) into the slots between the
@@ -415,7 +539,7 @@ def build_stream(T, addr, nLds, W=1, stage_base=None, nStage=0, hoist=True, pads
                     s_["base"] = hb + used
                     for q, tw in enumerate(s_["terms"]):
                         if not s_["late"][q]:
-                            terms.setdefault(term_key(s_), []).append((s_["base"] + q, tw))
+                            terms.setdefault(term_key(s_, tw), []).append((s_["base"] + q, tw))
                     add_pads(terms, s_, s_["base"])
                     used += rowlen(s_)             # the late terms keep their slot in the row: the folding lane fills it
                 if used > half:
@@ -441,7 +565,7 @@ def build_stream(T, addr, nLds, W=1, stage_base=None, nStage=0, hoist=True, pads
                         s_ = staged[k0]
                         base = cbase + used
                         for q, tw in enumerate(s_["terms"]):
-                            terms.setdefault(term_key(s_), []).append((base + q, tw))
+                            terms.setdefault(term_key(s_, tw), []).append((base + q, tw))
                         add_pads(terms, s_, base)
                         folds.setdefault((s_["fop"], 0, s_["aux"]), []).append(fold_item(s_, base, False))
                         used += rowlen(s_)
@@ -491,12 +615,12 @@ def copy_records(words, headers, pairs, nLds, W=1):
     return rg
 
 
-def class_stream(T, classname, defines, W=1, lds_slots=20000, hoist=True):
+def class_stream(T, classname, defines, W=1, lds_slots=20000, hoist=True, nested=True):
     """everything the device walk needs for one class"""
     sl = assign_slots(T, defines, lds_slots)
     addr, nLds = sl["addr"], sl["nLds"]
     st = build_stream(T, addr, nLds, W, stage_base=sl["stage_base"], nStage=sl["nStage"], hoist=hoist,
-                      pads=(sl["negzero"], sl["posinf"], sl["neginf"]))
+                      pads=(sl["negzero"], sl["posinf"], sl["neginf"]), one=sl["one"], nested=nested)
     words, headers = st["words"], st["headers"]
     rid, table = {}, []
     for g in sorted(st["granges"]):
@@ -540,10 +664,7 @@ def validate(words, headers, table, W, nLds, nAddr):
                 if not (1 <= cnt <= LANES and cn % 8 == 0 and cnt <= cn):
                     raise AssertionError("bad record count")
                 nlm = (flags >> F_NLATE_SHIFT) & 3 if kind == K_FOLD else 0
-                na = 1 + n if kind == K_SHORT else ((6 + 3 * NLATE if nlm else 5) if kind == K_FOLD else 4 + n)
-                if off < 0 or off + na * cn > len(words):
-                    raise AssertionError("record body outside the code array")
-                body = np.asarray(words[off:off + na * cn]).reshape(na, cn)
+                body = record_body(words, headers[8 * h:8 * h + 8])
                 dst = body[0]
                 if kind == K_FOLD:
                     rl = (body[1] + 7) // 8 * 8 if flags & F_PADDED else body[1]
@@ -556,9 +677,9 @@ def validate(words, headers, table, W, nLds, nAddr):
                             raise AssertionError("bad late-term count")
                         for q in range(NLATE):
                             act = body[5][:cnt] > q
-                            if (body[6 + 3 * q][:cnt][act] >= body[1][:cnt][act]).any() or body[6 + 3 * q].min() < 0:
+                            if (body[6 + 4 * q][:cnt][act] >= body[1][:cnt][act]).any() or body[6 + 4 * q].min() < 0:
                                 raise AssertionError("late term outside the row")
-                        ops = np.concatenate([ops] + [body[7 + 3 * q:9 + 3 * q] >> 1 for q in range(NLATE)])
+                        ops = np.concatenate([ops] + [body[7 + 4 * q:10 + 4 * q] >> 1 for q in range(NLATE)])
                 else:
                     ops = body[1:1 + n] >> 1 if kind == K_SHORT else body[2:4 + n] >> 1
                 if dst.min() < 0 or dst.max() >= nAddr or ops.min() < 0 or ops.max() >= nAddr:

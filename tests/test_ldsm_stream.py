@@ -53,6 +53,9 @@ def _fold(op, aux, xs, h0, h1):
 
 
 def _term(op, aux, v, sg):
+    if op == lsch.OP_PROD3:
+        with np.errstate(all="ignore"):
+            return v[0] * (v[1] * v[2])
     if op == lsch.OP_CLPTERM:
         with np.errstate(all="ignore"):
             return -v[0] / v[1] if v[1] < 0 else f64(np.finfo(float).max)
@@ -89,7 +92,8 @@ class Machine:
             h += 1
             if kind == lsch.K_BARRIER:
                 return h
-            rows = lambda j: w[off + j * cn:off + j * cn + cnt]       # noqa: E731
+            body = lsch.record_body(w, self.hd[h - 1])
+            rows = lambda j: [int(x) for x in body[j]]                # noqa: E731
             dst = rows(0)
             res = []
             if kind == lsch.K_SHORT:
@@ -102,9 +106,10 @@ class Machine:
                 if (flags >> lsch.F_NLATE_SHIFT) & 3:            # late terms: computed by the folding lane itself
                     nl = rows(5)
                     for q in range(cnt):
-                        for t in range(nl[q]):
-                            pos, wa, wb = (rows(6 + 3 * t + j)[q] for j in range(3))
-                            m[base[q] + pos] = m[wa >> 1] * m[wb >> 1]
+                        for t in range(nl[q]):                  # a * (b * c); c = the slot holding 1.0 for a plain product
+                            pos, wa, wb, wc = (rows(6 + 4 * t + j)[q] for j in range(4))
+                            with np.errstate(all="ignore"):
+                                m[base[q] + pos] = m[wa >> 1] * (m[wb >> 1] * m[wc >> 1])
                 for q in range(cnt):
                     # a padded row (ordered sums) is added up to the next multiple of 8: the pads must hold -0.0
                     nrow = -(-ln[q] // 8) * 8 if flags & lsch.F_PADDED else ln[q]
@@ -112,8 +117,8 @@ class Machine:
             else:
                 ln = rows(1)
                 for q in range(cnt):
-                    ws = [w[off + (2 + j) * cn + q] for j in range(2)][:lsch._DOT_SKIP.get(op, 0)] + \
-                         [w[off + (4 + k) * cn + q] for k in range(ln[q])]
+                    ws = [rows(2 + j)[q] for j in range(2)][:lsch._DOT_SKIP.get(op, 0)] + \
+                         [rows(4 + k)[q] for k in range(ln[q])]
                     res.append(_eval(op, aux, [m[x >> 1] for x in ws], [x & 1 for x in ws]))
             for q in range(cnt):
                 m[dst[q]] = res[q]
