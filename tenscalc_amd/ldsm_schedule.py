@@ -47,7 +47,9 @@ F_SUM = 3             # fold opcodes of K_FOLD records (the dot opcodes and I_su
 STAGE = 2048          # staging slots for the terms of long instructions
 F_GLOBAL_SRC, F_GLOBAL_DST, F_NEW_LEVEL = 1, 2, 4
 F_NLATE_SHIFT = 3      # flags bits 3-4 of a FOLD record: the largest late-term count among its lanes
-F_PADDED = 32          # FOLD record: every row is padded with -0.0 to a multiple of 8 terms (ordered sums)
+F_PADDED = 32          # FOLD record: every row is padded to a multiple of 8 terms with the operation's identity
+F_BARRIER_AFTER = 64   # the step ends behind this record: workgroup barrier (W > 1), saves a barrier record
+F_BARRIER_GLOBAL = 128  # ... and the step wrote to the instance's HBM array: the barrier must order those stores too
 _DOT_SKIP = {I.I_minus_dot: 0, I.I_minus_dot_div: 1, I.I_plus_minus_dot: 1, I.I_plus_minus_dot_div: 2}
 _LONG_OPS = {I.I_sum, I.I_sumprod, I.I_plus_sqr, I.I_plus_abs, I.I_min, I.I_min0, I.I_max, I.I_max0,
              I.I_max_abs, I.I_clp, I.I_minus_dot, I.I_minus_dot_div, I.I_plus_minus_dot, I.I_plus_minus_dot_div}
@@ -404,11 +406,14 @@ def build_stream(T, addr, nLds, W=1, stage_base=None, nStage=0, hoist=True, pads
             gdst = any(d >= nLds for r in recs for d, _ in r[5])
             for k in range(W):
                 first = True
-                for _, op, kind, nn, aux, part in per[k]:
-                    streams[k].append((op, kind, nn, aux, part, first))
+                for q, (_, op, kind, nn, aux, part) in enumerate(per[k]):
+                    bar = 0
+                    if W > 1 and q == len(per[k]) - 1:       # end of the step: the barrier rides on the wave's last record
+                        bar = F_BARRIER_AFTER | (F_BARRIER_GLOBAL if gdst else 0)
+                    streams[k].append((op, kind, nn, aux, part, first, bar))
                     first = False
-                if W > 1:
-                    streams[k].append(("barrier", gdst))    # end of the step
+                if W > 1 and not per[k]:
+                    streams[k].append(("barrier", gdst))    # a wave without work in this step only waits
 
         def cut(groups_, kind, cost):
             recs = []
@@ -585,8 +590,9 @@ def build_stream(T, addr, nLds, W=1, stage_base=None, nStage=0, hoist=True, pads
                 if r[0] == "barrier":
                     headers += [K_BARRIER << 8, 0, 0, 0, 0, F_NEW_LEVEL | (F_GLOBAL_DST if r[1] else 0), 0, 0]
                 else:
-                    op, kind, nn, aux, part, first = r
+                    op, kind, nn, aux, part, first, bar = r
                     _rec(words, headers, op, kind, nn, aux, part, nLds, first)
+                    headers[-3] |= bar
             rg.append((h0, len(headers) // 8))
         granges[g] = rg
         gstats[g] = (len(members), len(levels))
@@ -661,6 +667,8 @@ def validate(words, headers, table, W, nLds, nAddr):
                 if kind == K_BARRIER:
                     nb += 1
                     continue
+                if flags & F_BARRIER_AFTER:
+                    nb += 1
                 if not (1 <= cnt <= LANES and cn % 8 == 0 and cnt <= cn):
                     raise AssertionError("bad record count")
                 nlm = (flags >> F_NLATE_SHIFT) & 3 if kind == K_FOLD else 0

@@ -122,6 +122,8 @@ class Machine:
                     res.append(_eval(op, aux, [m[x >> 1] for x in ws], [x & 1 for x in ws]))
             for q in range(cnt):
                 m[dst[q]] = res[q]
+            if flags & lsch.F_BARRIER_AFTER:                         # the step ends behind this record
+                return h
         return h
 
     # entry points (writeCfunctionpergroup.m:513-852)
