@@ -43,6 +43,9 @@ NLATE = 2              # late terms a FOLD record can compute itself (body rows 
 OP_COPY = 60
 OP_CLPTERM = 61       # (b < 0) ? -a/b : DBL_MAX  -- one term of I_clp
 OP_PROD3 = 62         # a * (b * c): a term of a dot one of whose factors is itself a product of the level before
+F_MININF, F_MAXINF = 63, 64   # folds over one chunk of a long minimum / maximum: the chain starts from +inf / -inf
+SPLIT_MIN = 96        # a min / max / clp / long sum with more terms is folded in two levels (build_stream)
+SPLIT_CHUNK = 32
 F_SUM = 3             # fold opcodes of K_FOLD records (the dot opcodes and I_sumprod keep their own number)
 STAGE = 2048          # staging slots for the terms of long instructions
 F_GLOBAL_SRC, F_GLOBAL_DST, F_NEW_LEVEL = 1, 2, 4
@@ -342,7 +345,10 @@ def record_body(words, hdr):
 # the rows of every fold are padded to a multiple of 8 terms with the operation's identity (index into `pads`:
 # 0 = -0.0, 1 = +inf, 2 = -inf): the chain then needs neither a select nor a clamped address per term
 _PADDED_FOPS = {I.I_minus_dot: 0, I.I_minus_dot_div: 0, I.I_plus_minus_dot: 0, I.I_plus_minus_dot_div: 0, F_SUM: 0,
-                I.I_sumprod: 0, I.I_min: 1, I.I_min0: 1, I.I_clp: 1, I.I_max: 2, I.I_max0: 2}
+                I.I_sumprod: 0, I.I_min: 1, I.I_min0: 1, I.I_clp: 1, I.I_max: 2, I.I_max0: 2, F_MININF: 1, F_MAXINF: 2}
+# two-level folds: fold opcode of the instruction -> (fold opcode of a chunk, the first term leads the second level)
+_SPLIT = {I.I_sumprod: (F_SUM, False), I.I_min: (F_MININF, True), I.I_min0: (F_MININF, False), I.I_clp: (F_MININF, False),
+          I.I_max: (F_MAXINF, True), I.I_max0: (F_MAXINF, False)}
 _TERM = {  # long instruction -> (term opcode, operands per term, fold opcode); terms are evaluated in parallel, one per
     # lane, into consecutive staging slots; ONE lane then folds them strictly left to right
     I.I_minus_dot: ("prod", 2, I.I_minus_dot), I.I_minus_dot_div: ("prod", 2, I.I_minus_dot_div),
@@ -353,7 +359,26 @@ _TERM = {  # long instruction -> (term opcode, operands per term, fold opcode); 
 }
 
 
-def build_stream(T, addr, nLds, W=1, stage_base=None, nStage=0, hoist=True, pads=None, one=None, nested=True):
+def _split_chunk(fop, aux, nterm, split=True):
+    """chunk length of a two-level fold, or 0"""
+    if not split or fop not in _SPLIT or nterm <= SPLIT_MIN:
+        return 0
+    per = -(-100 // max(aux, 1)) if fop == I.I_sumprod else SPLIT_CHUNK
+    return per if nterm > per else 0
+
+
+def _staged_size(fop, aux, nterm, split=True):
+    """staging slots a staged instruction needs (rows padded to a multiple of 8; two-level folds: chunk rows + the
+    row of chunk results)"""
+    up8 = lambda n_: -(-n_ // 8) * 8         # noqa: E731
+    ch = _split_chunk(fop, aux, nterm, split)
+    if ch:
+        lens = [min(ch, nterm - k) for k in range(0, nterm, ch)]
+        return sum(up8(x) for x in lens) + up8(len(lens) + (1 if _SPLIT[fop][1] else 0))
+    return up8(nterm) if fop in _PADDED_FOPS else nterm
+
+
+def build_stream(T, addr, nLds, W=1, stage_base=None, nStage=0, hoist=True, pads=None, one=None, nested=True, split=True):
     """-> dict(words, headers, granges={group: [(first header, end header)]*W}, gstats)
 
     A LONG instruction (more than 8 operands: the dot products of the factorisation and of the triangular solves,
@@ -370,9 +395,20 @@ def build_stream(T, addr, nLds, W=1, stage_base=None, nStage=0, hoist=True, pads
     words, headers = [], []
     granges, gstats = {}, {}
 
+    def up8(n_):
+        return -(-n_ // 8) * 8
+
+    def chunks_of(s_):
+        """[(first term, length)] of the chunks of a two-level fold"""
+        n_, ch = len(s_["terms"]), s_["split"]
+        return [(k, min(ch, n_ - k)) for k in range(0, n_, ch)]
+
     def rowlen(s_):
         n_ = len(s_["terms"])
-        return -(-n_ // 8) * 8 if s_["fop"] in _PADDED_FOPS else n_
+        if s_.get("split"):
+            cks = chunks_of(s_)
+            return sum(up8(ln) for _, ln in cks) + up8(len(cks) + (1 if _SPLIT[s_["fop"]][1] else 0))
+        return up8(n_) if s_["fop"] in _PADDED_FOPS else n_
     # staging area = two alternating halves for terms computed one step ahead + the classic region, which must hold
     # the longest staged instruction of the class
     longest = 0
@@ -381,8 +417,10 @@ def build_stream(T, addr, nLds, W=1, stage_base=None, nStage=0, hoist=True, pads
             op = int(types[i - 1])
             tn = int(T.pars[T.parStart[i - 1]]) if op == I.I_sumprod else (_TERM[op][1] if op in _TERM else 1)
             nt = (ost[i] - ost[i - 1] - _DOT_SKIP.get(op, 0)) // max(tn, 1)
-            if nt <= nStage:
-                longest = max(longest, -(-nt // 8) * 8)
+            fop = I.I_sumprod if op == I.I_sumprod else (_TERM[op][2] if op in _TERM else None)
+            sz = _staged_size(fop, tn, nt, split)
+            if sz <= nStage:
+                longest = max(longest, sz)
     half = (max(0, nStage - longest) // 2) // 8 * 8 if hoist else 0
     cbase, cstage = (stage_base or 0) + 2 * half, nStage - 2 * half
     for g, members in enumerate(T.groups, 1):
@@ -472,7 +510,7 @@ def build_stream(T, addr, nLds, W=1, stage_base=None, nStage=0, hoist=True, pads
                     top, tn, fop = _TERM[op]
                 skip = _DOT_SKIP.get(op, 0)
                 nterm = (len(a) - skip) // tn
-                if nStage and tn <= NSHORT and -(-nterm // 8) * 8 <= cstage and (len(a) - skip) % tn == 0:
+                if nStage and tn <= NSHORT and _staged_size(fop, aux, nterm, split) <= cstage and (len(a) - skip) % tn == 0:
                     tl, late = [], []
                     for q in range(nterm):
                         ids = list(ops[skip + q * tn:skip + (q + 1) * tn])
@@ -493,13 +531,23 @@ def build_stream(T, addr, nLds, W=1, stage_base=None, nStage=0, hoist=True, pads
                         late.append(prev is not None and any(T.group[j] == g and T.used[j] and lvl[j] >= prev for j in ids))
                         if any(T.group[j] == g and T.used[j] and lvl[j] >= l_ for j in ids):
                             raise AssertionError(f"instruction {i}: a term needs a value of its own level")
-                    staged.append(dict(op=op, fop=fop, aux=aux, d=d, heads=a[:skip], top=top, tn=tn, terms=tl, late=late))
+                    s_ = dict(op=op, fop=fop, aux=aux, d=d, heads=a[:skip], top=top, tn=tn, terms=tl, late=late)
+                    # A long minimum / maximum does not depend on the order of its operands except through NaNs and
+                    # the signs of zeros, and a long sum of products is DEFINED by the reference as a sum of
+                    # statements of <= MAX_TERMS_PERLINE factors (instructionsTableUTHash.c:1003-1012): the chunks
+                    # (the reference's own lines for the sum) are folded by one lane each, a second fold combines
+                    # the chunk results in order.  Chunks of a minimum start from +inf (a NaN is skipped as in the
+                    # reference's chain); where the reference starts from its first operand that operand leads the
+                    # second level, so a NaN there sticks and the first of equal zeros stays.
+                    if _split_chunk(fop, aux, nterm, split):
+                        s_["split"] = _split_chunk(fop, aux, nterm, split)
+                    staged.append(s_)
                 else:
                     long_.setdefault((op, 0, aux), []).append((d, a))
             for key, items in long_.items():
                 long_[key] = sorted(items, key=lambda it: -len(it[1]))      # similar lengths share a record
             staged.sort(key=lambda s_: -len(s_["terms"]))
-            hoist = bool(staged) and idx > 0 and half >= 64
+            hoist = bool(staged) and idx > 0 and half >= 64 and not any(s_.get("split") for s_ in staged)
             for s_ in staged:
                 nl = sum(s_["late"])
                 if nl and not (s_["top"] == "prod" and s_["tn"] == 2 and nl <= NLATE):
@@ -524,12 +572,15 @@ def build_stream(T, addr, nLds, W=1, stage_base=None, nStage=0, hoist=True, pads
                 return (OP_PROD3, 3, 0) if len(tw) == 3 and s_["tn"] == 2 else (I.I_sumprod, s_["tn"], s_["tn"])
             return (s_["top"], s_["tn"], 0)
 
-        def add_pads(terms, s_, base):
+        def pad_row(terms, fop, base, n_):
             """the operation's identity (-0.0 for sums, +inf for minima, -inf for maxima) into the slots between the
-            end of the row and the next multiple of 8"""
-            if s_["fop"] in _PADDED_FOPS:
-                for q in range(len(s_["terms"]), rowlen(s_)):
-                    terms.setdefault((OP_COPY, 1, 0), []).append((base + q, [pads[_PADDED_FOPS[s_["fop"]]] * 2]))
+            end of a row of n_ terms and the next multiple of 8"""
+            if fop in _PADDED_FOPS:
+                for q in range(n_, up8(n_)):
+                    terms.setdefault((OP_COPY, 1, 0), []).append((base + q, [pads[_PADDED_FOPS[fop]] * 2]))
+
+        def add_pads(terms, s_, base):
+            pad_row(terms, s_["fop"], base, len(s_["terms"]))
         toggle = 0
         ahead = []              # records of the NEXT level's early terms, to ride on this level's last step
         for idx, lv in enumerate(info):
@@ -566,13 +617,33 @@ def build_stream(T, addr, nLds, W=1, stage_base=None, nStage=0, hoist=True, pads
                 k0 = 0
                 while True:
                     terms, folds, used = {}, {}, 0
+                    extra, finals = {}, {}      # two-level folds: copies / pads beside the chunk folds, second level
                     while k0 < len(staged) and used + rowlen(staged[k0]) <= cstage:
                         s_ = staged[k0]
                         base = cbase + used
-                        for q, tw in enumerate(s_["terms"]):
-                            terms.setdefault(term_key(s_, tw), []).append((base + q, tw))
-                        add_pads(terms, s_, base)
-                        folds.setdefault((s_["fop"], 0, s_["aux"]), []).append(fold_item(s_, base, False))
+                        if s_.get("split"):
+                            fop1, lead = _SPLIT[s_["fop"]]
+                            cks = chunks_of(s_)
+                            row2 = base + sum(up8(ln) for _, ln in cks)
+                            off2 = 1 if lead else 0
+                            b_ = base
+                            for k, (t0, ln) in enumerate(cks):
+                                for q in range(ln):
+                                    tw = s_["terms"][t0 + q]
+                                    terms.setdefault(term_key(s_, tw), []).append((b_ + q, tw))
+                                pad_row(terms, fop1, b_, ln)
+                                folds.setdefault((fop1, 0, 0), []).append((row2 + off2 + k, [ln, 2, 2, b_]))
+                                b_ += up8(ln)
+                            if lead:
+                                extra.setdefault((OP_COPY, 1, 0), []).append((row2, [base * 2]))
+                            pad_row(extra, s_["fop"], row2, len(cks) + off2)
+                            fop2 = F_SUM if s_["fop"] == I.I_sumprod else s_["fop"]
+                            finals.setdefault((fop2, 0, 0), []).append((s_["d"], [len(cks) + off2, 2, 2, row2]))
+                        else:
+                            for q, tw in enumerate(s_["terms"]):
+                                terms.setdefault(term_key(s_, tw), []).append((base + q, tw))
+                            add_pads(terms, s_, base)
+                            folds.setdefault((s_["fop"], 0, s_["aux"]), []).append(fold_item(s_, base, False))
                         used += rowlen(s_)
                         k0 += 1
                     emit(recs + cut(terms, K_SHORT, lambda nn, it: nn + 6))
@@ -580,7 +651,10 @@ def build_stream(T, addr, nLds, W=1, stage_base=None, nStage=0, hoist=True, pads
                     for key, items in folds.items():
                         folds[key] = sorted(items, key=lambda it: -it[1][0])
                     last = k0 >= len(staged)
-                    emit(cut(folds, K_FOLD, lambda nn, it: it[1][0] // 2 + 8) + (ahead_next if last else []))
+                    emit(cut(folds, K_FOLD, lambda nn, it: it[1][0] // 2 + 8) + cut(extra, K_SHORT, lambda nn, it: nn + 6)
+                         + (ahead_next if last and not finals else []))
+                    if finals:
+                        emit(cut(finals, K_FOLD, lambda nn, it: it[1][0] // 2 + 8) + (ahead_next if last else []))
                     if last:
                         break
         rg = []
@@ -621,12 +695,12 @@ def copy_records(words, headers, pairs, nLds, W=1):
     return rg
 
 
-def class_stream(T, classname, defines, W=1, lds_slots=20000, hoist=True, nested=True):
+def class_stream(T, classname, defines, W=1, lds_slots=20000, hoist=True, nested=True, split=True):
     """everything the device walk needs for one class"""
     sl = assign_slots(T, defines, lds_slots)
     addr, nLds = sl["addr"], sl["nLds"]
     st = build_stream(T, addr, nLds, W, stage_base=sl["stage_base"], nStage=sl["nStage"], hoist=hoist,
-                      pads=(sl["negzero"], sl["posinf"], sl["neginf"]), one=sl["one"], nested=nested)
+                      pads=(sl["negzero"], sl["posinf"], sl["neginf"]), one=sl["one"], nested=nested, split=split)
     words, headers = st["words"], st["headers"]
     rid, table = {}, []
     for g in sorted(st["granges"]):

@@ -44,6 +44,12 @@ def _fold(op, aux, xs, h0, h1):
                 if acc > x:
                     acc = x
             return acc
+        if op in (lsch.F_MININF, lsch.F_MAXINF):       # one chunk of a long minimum / maximum: from +-inf
+            acc = f64(np.inf if op == lsch.F_MININF else -np.inf)
+            for x in xs:
+                if (acc > x) if op == lsch.F_MININF else (acc < x):
+                    acc = x
+            return acc
         if op == lsch.F_SUM:
             acc = xs[0]
             for x in xs[1:]:
@@ -255,3 +261,28 @@ def test_ldsm_validator_rejects_bad_addresses(sls_spec):
     w[int(hd[0, 4])] = cs["nLds"] + cs["nGlob"] + 5        # destination of the first record outside the state
     with pytest.raises(AssertionError):
         lsch.validate(w, cs["headers"], cs["table"], cs["W"], cs["nLds"], cs["nLds"] + cs["nGlob"])
+
+
+@pytest.mark.parametrize("op", [I.I_min, I.I_min0, I.I_max, I.I_max0, I.I_clp])
+def test_two_level_fold_equals_the_reference_chain(op):
+    """ldsm_schedule._SPLIT: a long minimum / maximum folded chunk by chunk (chunks from +-inf, the reference's leading
+    operand in front of the chunk results where its chain starts from it) gives the value of the reference's single
+    chain bit for bit -- NaNs (sticky in first position, skipped elsewhere), signed zeros (the first of equal zeros
+    stays), infinities and DBL_MAX included"""
+    rng = np.random.RandomState(7)
+    fop1, lead = lsch._SPLIT[op]
+    special = [np.nan, 0.0, -0.0, np.inf, -np.inf, np.finfo(float).max, -np.finfo(float).max, 1.0, -1.0]
+    for trial in range(400):
+        n = int(rng.randint(97, 260))
+        x = rng.randn(n)
+        for _ in range(int(rng.randint(0, 12))):
+            x[rng.randint(n)] = special[rng.randint(len(special))]
+        if trial % 5 == 0:
+            x[0] = special[trial // 5 % len(special)]
+        if trial % 7 == 0:
+            x[:] = np.where(rng.rand(n) < .5, 0.0, -0.0)
+        xs = [f64(v) for v in x]
+        ref = _fold(op, 0, xs, f64(0), f64(0))
+        parts = [_fold(fop1, 0, xs[k:k + lsch.SPLIT_CHUNK], f64(0), f64(0)) for k in range(0, n, lsch.SPLIT_CHUNK)]
+        got = _fold(op, 0, ([xs[0]] if lead else []) + parts, f64(0), f64(0))
+        assert (got != got and ref != ref) or (got == ref and np.signbit(got) == np.signbit(ref)), (trial, got, ref)
