@@ -95,7 +95,7 @@ def test_l1l2_interp_bit_exact(libs, tmp_path):
     assert np.array_equal(got, ref)
 
 
-@pytest.mark.parametrize("variant", ["sls_ldsm", "sls_ldsm4"])
+@pytest.mark.parametrize("variant", ["sls_ldsm", "sls_ldsm4", "sls_ldsm8"])
 def test_sls_ldsm_bit_exact(libs, sls_spec, tmp_path, variant):
     """LDS-resident tape machine (csrc/tc_ldsm.hip.inc): one instance per workgroup of 1 / 4 wavefronts, the lanes
     execute different instructions, long sums split into parallel terms + an ordered fold: same bits as the oracle"""
@@ -110,7 +110,7 @@ def test_sls_ldsm_bit_exact(libs, sls_spec, tmp_path, variant):
     assert np.array_equal(got, ref)
 
 
-@pytest.mark.parametrize("variant", ["dcmotor_ldsm4", "dcmotor_ldsm_cold"])
+@pytest.mark.parametrize("variant", ["dcmotor_ldsm4", "dcmotor_ldsm8", "dcmotor_ldsm_cold"])
 def test_dcmotor_ldsm_bit_exact(libs, tmp_path, variant):
     """nG > 0, second LDL; `ldsm_cold`: an LDS budget too small for the state, so part of it lives in the
     per-instance HBM array (global operand / destination path of the device walk)"""
@@ -139,8 +139,8 @@ def test_l1l2_ldsm_bit_exact(libs, tmp_path):
 def test_quadcopter_T100_ldsm_vs_interp_vs_oracle(libs, tmp_path):
     """BASELINE configs[4] as written (T=100, 1406x1406 KKT, 67 k instructions), B = 64.
 
-    (1) The two device back-ends -- interp (one thread per instance, state in HBM) and ldsm4 (one instance per
-    workgroup, LDL factor and solves in LDS) -- evaluate the same tape with the same device libm in the same
+    (1) The two device back-ends -- interp (one thread per instance, state in HBM) and ldsm4 / ldsm8 (one instance per
+    workgroup of 4 / 8 wavefronts, LDL factor and solves in LDS) -- evaluate the same tape with the same device libm in the same
     operand order: status, iteration count and all 2404 outputs are BIT-IDENTICAL between them over complete
     solves (20..371 iterations).
     (2) Against the oracle the tolerance is on few-step quantities (device pow() and glibc's differ by 1 ulp on a
@@ -163,7 +163,7 @@ def test_quadcopter_T100_ldsm_vs_interp_vs_oracle(libs, tmp_path):
     save_tape(spec.tape, tape)
     c = spec.classname
     res = {}
-    for tag in ("quadcopter_ldsm4", "quadcopter_interp"):
+    for tag in ("quadcopter_ldsm4", "quadcopter_ldsm8", "quadcopter_interp"):
         obj = _load(libs[tag], B)
         for n in names:
             obj.set(n, stacked[n])
@@ -176,9 +176,11 @@ def test_quadcopter_T100_ldsm_vs_interp_vs_oracle(libs, tmp_path):
                 few[mi] = np.concatenate([a.reshape(B, -1) for a in obj.getOutputs()], axis=1)
             out = obj.getOutputs(as_dict=True)
         obj.close()
-    a, b = res["quadcopter_ldsm4"], res["quadcopter_interp"]
-    print("\nquadcopter T=100, B=64: ldsm4 %.0f ms, interp %.0f ms; iterations %d..%d" % (a[3] * 1e3, b[3] * 1e3, a[1].min(), a[1].max()))
+    a, b, a8 = res["quadcopter_ldsm4"], res["quadcopter_interp"], res["quadcopter_ldsm8"]
+    print("\nquadcopter T=100, B=64: ldsm4 %.0f ms, ldsm8 %.0f ms, interp %.0f ms; iterations %d..%d"
+          % (a[3] * 1e3, a8[3] * 1e3, b[3] * 1e3, a[1].min(), a[1].max()))
     assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1]) and np.array_equal(a[2], b[2], equal_nan=True)
+    assert np.array_equal(a8[0], b[0]) and np.array_equal(a8[1], b[1]) and np.array_equal(a8[2], b[2], equal_nan=True)
     assert (a[0] == 0).all()
     nref = 12
     sub = {f"{c}_set_{n}": stacked[n][:nref] for n in names}
