@@ -162,9 +162,9 @@ class Machine:
         self.clean -= set(e["children"])
 
 
-def _check(spec, data, tape_oracle, args, W=1, lds_slots=20000):
+def _check(spec, data, tape_oracle, args, W=1, lds_slots=20000, stream_kw=None):
     T, c, D = spec.tape, spec.classname, spec.defines
-    cs = lsch.class_stream(T, c, D, W=W, lds_slots=lds_slots)
+    cs = lsch.class_stream(T, c, D, W=W, lds_slots=lds_slots, **(stream_kw or {}))
     o = tape_oracle(T, c)
     mach = Machine(T, cs)
 
@@ -231,9 +231,10 @@ def test_ldsm_stream_sls(sls_spec, tape_oracle):
     assert {lsch.K_SHORT, lsch.K_FOLD} <= kinds            # the 300-operand sums are staged and folded
 
 
-@pytest.mark.parametrize("W", [1, 4])
+@pytest.mark.parametrize("W", [1, 4, 8])
 def test_ldsm_stream_dcmotor(native_built, tape_oracle, tmp_path, W):
-    """nG > 0 (second LDL for initDualEqX__), W = 4: records of every step spread over 4 waves + barriers"""
+    """nG > 0 (second LDL for initDualEqX__), W = 4 / 8: records of every step spread over the waves, the barrier
+    riding on each wave's last record of the step"""
     from tenscalc_amd.problems.mpc_dcmotor import SOLVE_ARGS, dcmotor_data, mpc_dcmotor
     spec = mpc_dcmotor(folder=str(tmp_path))
     _check(spec, dcmotor_data(7), tape_oracle, SOLVE_ARGS, W)
@@ -286,3 +287,16 @@ def test_two_level_fold_equals_the_reference_chain(op):
         parts = [_fold(fop1, 0, xs[k:k + lsch.SPLIT_CHUNK], f64(0), f64(0)) for k in range(0, n, lsch.SPLIT_CHUNK)]
         got = _fold(op, 0, ([xs[0]] if lead else []) + parts, f64(0), f64(0))
         assert (got != got and ref != ref) or (got == ref and np.signbit(got) == np.signbit(ref)), (trial, got, ref)
+
+
+@pytest.mark.parametrize("kw", [dict(hoist=False), dict(nested=False), dict(split=False), dict()])
+def test_ldsm_stream_schedule_options_agree(native_built, tape_oracle, tmp_path, kw):
+    """every scheduling step of DESIGN.md 3.9 -- terms staged one step ahead + late terms in the folding lane (hoist),
+    nested products (nested), two-level folds of the long reductions (split) -- can be switched off, and every
+    combination walks to the oracle's values: the steps change WHEN an operation runs, never what it computes"""
+    from tenscalc_amd.problems.mpc_dcmotor import SOLVE_ARGS, dcmotor_data, mpc_dcmotor
+    spec = mpc_dcmotor(folder=str(tmp_path))
+    cs = _check(spec, dcmotor_data(9), tape_oracle, SOLVE_ARGS, W=4, stream_kw=kw)
+    hd = np.asarray(cs["headers"]).reshape(-1, 8)
+    steps = int(((hd[:, 0] >> 8) == lsch.K_BARRIER).sum() + (((hd[:, 0] >> 8) != lsch.K_BARRIER) & ((hd[:, 5] & lsch.F_BARRIER_AFTER) > 0)).sum())
+    print(kw, "records", len(hd), "barriers (all waves)", steps)
