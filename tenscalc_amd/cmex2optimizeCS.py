@@ -44,6 +44,33 @@ def packVariables(variables, name, *exprs):
     return (out, where) + tuple(res)
 
 
+def variableIndices(u, optimizationVariables, where, sensitivityVariables):
+    """lib/private/variableIndices.m: flags, over the packed vector u, of the optimization variables (or of the
+    selected entries v[...] of one) with respect to which the cost sensitivity is wanted"""
+    import numpy as np
+    isSensitivity = np.zeros(u.size[0], dtype=bool)
+    for k, sv in enumerate(sensitivityVariables):
+        sv = tc.toT(sv)
+        ind = None
+        if sv.op == "reshape" and sv.args[0].op == "subsref":       # v[i, :] : the dropped dimension is a reshape here
+            sv = sv.args[0]
+        if sv.op == "subsref":
+            base = sv.args[0]
+            lin = np.arange(tc._prod(base.size)).reshape(base.size, order="F")
+            ind = lin[np.ix_(*[list(x) for x in sv.par])].ravel(order="F")
+            sv = base
+        if sv.op != "variable":
+            raise ValueError("all sensitivityVariables must be of the type 'variable' (%dth is of type '%s')" % (k + 1, sv.op))
+        for v, (a, b) in zip(optimizationVariables, where):
+            if v.op == "variable" and v.par == sv.par:
+                pos = np.arange(a, b)
+                isSensitivity[pos if ind is None else pos[ind]] = True
+                break
+        else:
+            raise ValueError(f"sensitivityVariable {sv.par} is not an optimizationVariable")
+    return isSensitivity
+
+
 def parseConstraints(code, classname, constraints):
     """lib/private/parseConstraints.m:74-135"""
     Gc, Fc, nus, lambdas = [], [], [], []
@@ -98,12 +125,16 @@ def cmex2optimizeCS(*, classname, objective, optimizationVariables, constraints=
                     addEye2Hessian=True, adjustAddEye2Hessian=True, useInertia=False,
                     addEye2HessianUtolerance=1e-6, smallerNewtonMatrix=False, useLDL=True,
                     useUmfpack=False, allowSave=False, solverVerboseLevel=0, hoist=False, lambdaUpdate="multiplicative",
-                    **ignored):
+                    sensitivityVariables=(), **ignored):
     """Generate an interior-point solver for ``min objective s.t. constraints``.
 
     ``lambdaUpdate='additive'`` generates the reference's original assembly lib/ipmPD_CS.m (``switch 1`` at
     cmex2optimizeCS.m:84-93) instead of ipmPD_CStimesLambda.m; only with it are ``skipAffine=False`` (Mehrotra
     predictor step, ipmPD_CSsolver.c:576-665) and ``smallerNewtonMatrix=True`` available.
+
+    ``sensitivityVariables`` (optimization variables, or ``v[...]`` entries of one: lib/private/variableIndices.m)
+    adds the cost-sensitivity outputs of ipmPD_CS.m:478-503 -- ``Du1_``, ``DfDu1_``, ``D2fDu1_`` placeholders in
+    ``outputExpressions``; additive assembly only, as in the reference.
 
     ``hoist=True`` (not a reference option) applies tenscalc_amd/hoist.py: products of
     parameter-only factors in the derivatives are contracted first, so they are evaluated once
@@ -113,7 +144,7 @@ def cmex2optimizeCS(*, classname, objective, optimizationVariables, constraints=
     options raise too, as FunParTools' setParameters does for the reference."""
     if ignored:
         accepted_noop = {"compilerOptimization", "compileGateways", "compileLibrary", "compileStandalones",
-                         "callType", "sensitivityVariables", "simulinkLibrary", "dummyLibrary", "pedigreeClass",
+                         "callType", "simulinkLibrary", "dummyLibrary", "pedigreeClass",
                          "executeScript", "useSparsityPatterns", "minInstructions4loop", "maxInstructionsPerFunction",
                          "absolutePath", "serverProgramName", "serverAddress", "port", "profiling", "umfpack",
                          "debugConvergence", "debugConvergenceThreshold", "scratchbookType", "fastRedundancyCheck",
@@ -177,10 +208,15 @@ def cmex2optimizeCS(*, classname, objective, optimizationVariables, constraints=
     if hoist:
         from .hoist import Hoister
         rewrite = Hoister(parameters).rewrite
+    isSensitivity = variableIndices(u, optimizationVariables, where, list(sensitivityVariables))
+    if isSensitivity.any() and lambdaUpdate != "additive":
+        raise NotImplementedError("sensitivityVariables need lambdaUpdate='additive': ipmPD_CStimesLambda: isSensitivity=true "
+                                  "not implemented, use ipmPD_CS.m (ipmPD_CStimesLambda.m:31-33)")
     if lambdaUpdate == "additive":
         Tout = ipmPD_CS(code, u, objective_u, F, G, lam, nu, addEye2Hessian=addEye2Hessian, scaleCost=scaleCost,
                         scaleInequalities=scaleInequalities, classname=classname, rewrite=rewrite,
-                        skipAffine=bool(skipAffine) or nF == 0, smallerNewtonMatrix=bool(smallerNewtonMatrix))
+                        skipAffine=bool(skipAffine) or nF == 0, smallerNewtonMatrix=bool(smallerNewtonMatrix),
+                        isSensitivity=isSensitivity)
     else:
         Tout = ipmPD_CStimesLambda(code, u, objective_u, F, G, lam, nu,
                                    addEye2Hessian=addEye2Hessian, scaleCost=scaleCost,

@@ -9,6 +9,8 @@ loop calls (``lib/ipmPD_CSsolver.c:28-51``).
 """
 from __future__ import annotations
 
+import numpy as np
+
 from . import tcalculus as tc
 from .tcalculus import (Teye, Tones, Tvariable, Tzeros, cat, clp, compose, diag, full,
                         gradient, hessian, ldl, ldl_d, ldl_l, mldivide, norminf,
@@ -169,7 +171,7 @@ def ipmPD_CStimesLambda(code, u, f, F, G, lam, nu, *, addEye2Hessian=True, scale
 
 
 def ipmPD_CS(code, u, f, F, G, lam, nu, *, addEye2Hessian=True, scaleCost=0.0, scaleInequalities=True,
-             classname="cls", skipAffine=True, smallerNewtonMatrix=False, rewrite=None):
+             classname="cls", skipAffine=True, smallerNewtonMatrix=False, rewrite=None, isSensitivity=None):
     """The reference's ORIGINAL assembly, /root/reference/lib/ipmPD_CS.m (packOptimizationVariables=true, LDL, no
     trust region): ADDITIVE update of lambda, optional Mehrotra predictor ("affine") step -- skipAffine=False:
     entry points getMaxAlphas_a__, getMinF_a__, getRho__ for lib/ipmPD_CSsolver.c:576-665 -- and optional
@@ -326,4 +328,29 @@ def ipmPD_CS(code, u, f, F, G, lam, nu, *, addEye2Hessian=True, scaleCost=0.0, s
         srcs.append(lam + alphaDualIneq * dLambda_s)                         # ADDITIVE update (:315,408)
     code.declareCopy(dsts, srcs, "updatePrimalDual__")
     out["b"], out["dx"] = b_s, dx_s
+    # cost sensitivity with respect to some of the optimization variables (ipmPD_CS.m:478-503): with u = (u1, u2),
+    # u1 the sensitivity variables, the other unknowns z = (u2, nu, lambda) solve Hess1*dz = B1*du1 around the
+    # solution: Du1 = dz/du1, DfDu1 = Lf_u1, D2fDu1 = WW(u1,u1) + WW(u1,z)*Du1.  Outputs only ('Du1_', 'DfDu1_',
+    # 'D2fDu1_' in outputExpressions); nothing of the Newton iteration changes.
+    isSensitivity = np.zeros(nU, dtype=bool) if isSensitivity is None else np.asarray(isSensitivity, dtype=bool)
+    if isSensitivity.shape != (nU,):
+        raise ValueError("isSensitivity: one flag per packed optimization variable expected")
+    if isSensitivity.any():
+        if smallerNewtonMatrix:
+            raise NotImplementedError("ipmPD_CS: computation of sensitivity not implemented for smallerNewtonMatrix "
+                                      "(ipmPD_CS.m:479-481)")
+        s1 = [int(k) for k in np.flatnonzero(isSensitivity)]
+        rest = [int(k) for k in np.flatnonzero(~isSensitivity)] + list(range(nU, nU + nG + nF))
+        out["DfDu1"] = Lf_u[s1]
+        D2 = WW[s1, s1]
+        if (~isSensitivity).any():
+            out["Hess1"] = WW[rest, rest]
+            out["B1"] = -WW[rest, s1]
+            nr = int((~isSensitivity).sum())
+            factor_Hess1 = ldl(out["Hess1"], classname + "_Hess1", stages=[0] * nr + [1] * nG + [0] * nF)
+            out["Du1"] = mldivide(factor_Hess1, out["B1"])
+            D2 = D2 + WW[s1, rest] * out["Du1"]
+        else:
+            out["Du1"] = Tzeros((0, len(s1)))
+        out["D2fDu1"] = D2
     return out

@@ -53,3 +53,21 @@ def opcode_zoo(N=12, n=4, classname="tmp_opcode_zoo", **options):
     return cmex2optimizeCS(classname=classname, objective=J, optimizationVariables=[x],
                            constraints=[x >= 0, x <= .05], outputExpressions=outs, outputNames=names,
                            parameters=[A, b], **options)
+
+
+def sensitivity_ls(N=12, n=3, ns=2, classname="tmp_sens", **options):
+    """constrained least squares in z = (p, x) with p declared as SENSITIVITY variables (cmex2optimizeCS's
+    ``sensitivityVariables``, lib/ipmPD_CS.m:478-503): outputs Du1 = d(x, nu, lambda)/dp, DfDu1, D2fDu1 next to the
+    solver's Hess and Lf_u"""
+    A = tc.Tvariable("A", (N, ns + n))
+    b = tc.Tvariable("b", (N,))
+    x = tc.Tvariable("x", (n,))
+    p = tc.Tvariable("p", (ns,))
+    J = tc.norm2(A * tc.cat(1, p, x) - b) / N
+    nZ = ns + n + 1 + n
+    outs = [J, x, p, tc.Tvariable("Hess_", (nZ, nZ)), tc.Tvariable("Lf_u_", (ns + n,)), tc.Tvariable("Du1_", (nZ - ns, ns)),
+            tc.Tvariable("DfDu1_", (ns,)), tc.Tvariable("D2fDu1_", (ns, ns))]
+    return cmex2optimizeCS(classname=classname, objective=J, optimizationVariables=[p, x], sensitivityVariables=[p],
+                           constraints=[tc.tsum(x) == .1, x >= 0], outputExpressions=outs,
+                           outputNames=["J", "x", "p", "Hess", "Lf_u", "Du1", "DfDu1", "D2fDu1"], parameters=[A, b],
+                           lambdaUpdate="additive", **options)
