@@ -1755,7 +1755,9 @@ def build_class(spec, fp_contract="fast", arch="gfx950", opt="-O3", block=64, fo
             os.path.join(CSRC, "tc_wave.hip.inc"), os.path.join(CSRC, "tc_interp.hip.inc"),
             os.path.join(CSRC, "tc_ldsm.hip.inc"),
             os.path.join(INCLUDE, "tenscalc_hip.h")]
-    h = hashlib.sha256((src + " ".join(flags)).encode())
+    # (the digest must not depend on where the tree lies: the libraries built here travel to the GPU box, whose
+    # checkout is at another path -- with the include directories hashed in, every library was rebuilt there)
+    h = hashlib.sha256((src + " ".join(f for f in flags if f not in (CSRC, INCLUDE))).encode())
     for d in deps:
         h.update(open(d, "rb").read())
     stamp = os.path.join(outdir, f"{cls}{suffix}.stamp")
