@@ -581,8 +581,7 @@ def build_stream(T, addr, nLds, W=1, stage_base=None, nStage=0, hoist=True, pads
 
         def add_pads(terms, s_, base):
             pad_row(terms, s_["fop"], base, len(s_["terms"]))
-        toggle = 0
-        ahead = []              # records of the NEXT level's early terms, to ride on this level's last step
+        toggle = 0               # which staging half the next hoisted level's early terms go to
         for idx, lv in enumerate(info):
             recs = cut(lv["short"], K_SHORT, lambda nn, it: nn + 6) + cut(lv["long_"], K_LONG, lambda nn, it: len(it[1]) + 8)
             nxt = info[idx + 1] if idx + 1 < len(info) else None
