@@ -72,7 +72,7 @@ def main():
         return bench_config(args)
     args.variant = args.variant or "w8x"
     import __graft_entry__ as g
-    sls_variants = [v for v, kw in g.VARIANT_KW.items() if kw.get("body", "code") == "code"]
+    sls_variants = [v for v, kw in g.VARIANT_KW.items() if kw.get("body", "code") == "code" and v not in g.CONFIG_ONLY]
     if args.variant not in sls_variants:
         ap.error("--variant for --config sls: " + ", ".join(sls_variants))
 
@@ -360,6 +360,8 @@ def bench_config(args):
     mod = importlib.import_module(modname)
     SOLVE = mod.SOLVE_ARGS
     variant = args.variant or var0                       # any key of __graft_entry__.VARIANT_KW (interp8, ldsm4, strict, ...)
+    if args.config == "dcmotor" and not args.variant and 0 < args.batch <= 8192:
+        variant = "w32x"      # one GPU's share of the 8-GPU sweep: the wave-cooperative lowering (LDS-resident state) wins
     B = args.batch or B0
     spec = getattr(mod, mk)(folder=g.GENERATED)
     kw = dict(g.VARIANT_KW[variant])

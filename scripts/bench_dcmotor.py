@@ -17,9 +17,10 @@ spec = mpc_dcmotor(folder=g.GENERATED)
 if variant == "strict":
     so = spec.build(**g.VARIANT_KW["strict"])
 else:                                    # e.g. w64: 64 lanes share one instance, state in LDS
-    kw = dict(g.VARIANT_KW["w8"])
-    share = variant.endswith("s")           # e.g. w64s: LDS slots shared by life time
-    kw.update(lanes=int(variant[1:].rstrip("s")), tag=variant, inline_max=32, share=share)
+    exact = variant.endswith("x")           # e.g. w32x: the bit-exact wave-cooperative lowering
+    kw = dict(g.VARIANT_KW["w8x" if exact else "w8"])
+    share = variant.endswith("s") or exact  # e.g. w64s: LDS slots shared by life time
+    kw.update(lanes=int(variant[1:].rstrip("sx")), tag=variant, inline_max=32, share=share)
     so = spec.build(**kw)
 data = [dcmotor_data(k) for k in range(B)]
 names = [n for n, _ in spec.parameters + spec.variables]

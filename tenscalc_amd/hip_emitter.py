@@ -1732,11 +1732,33 @@ def build_class(spec, fp_contract="fast", arch="gfx950", opt="-O3", block=64, fo
                 branch_free_tails=True, exact=False, stg_blocks=0, lds_slots=20000, ilp=False):
     """Emit <cls>.hip (+ <cls>.h, <cls>.tape) and compile lib<cls>.so with hipcc for gfx950.
     Mirrors the createGateway/compile step of cmex2optimizeCS.m:403-417."""
-    from .tapeio import save_tape
+    from .tapeio import save_tape, tape_records, _rec
     cls = spec.classname
     outdir = outdir or os.path.join(spec.folder, f"@{cls}")
     os.makedirs(outdir, exist_ok=True)
     suffix = f"_{tag}" if tag else ""
+    # Quick key: the tape, the options and the generator's own sources.  If it matches the one recorded with the
+    # library the source need not be emitted again just to be hashed -- lowering mpc_dcmotor for 32 lanes with slot
+    # sharing takes two minutes, and every test module asks build() for the whole list of libraries.
+    kq = hashlib.sha256()
+    for name, arr in tape_records(spec.tape).items():
+        kq.update(_rec(name, arr))
+    kq.update(repr((cls, sorted(spec.defines.items()), [(n, tuple(sz)) for n, sz in spec.outputs], fp_contract, arch, opt, block,
+                    stats, tag, tuple(extra_flags), roll, min_waves, lanes, recip, fast_div, inline_max, reg_budget, scratch,
+                    body, waves, fuse, static_clean, forward, rcache, lds_state, share, branch_free_tails, exact, stg_blocks,
+                    lds_slots, ilp, os.environ.get("TC_LDS_PAD_SLOTS", ""), os.environ.get("TC_SWEEP_UNROLL", ""))).encode())
+    for f_ in sorted(os.listdir(HERE)):
+        if f_.endswith(".py"):
+            kq.update(open(os.path.join(HERE, f_), "rb").read())
+    for d_ in (CSRC, INCLUDE):
+        for f_ in sorted(os.listdir(d_)):
+            if f_.endswith((".inc", ".h")):
+                kq.update(open(os.path.join(d_, f_), "rb").read())
+    quick = kq.hexdigest()
+    so_ = os.path.join(outdir, f"lib{cls}{suffix}.so")
+    qfile = os.path.join(outdir, f"{cls}{suffix}.key")
+    if not force and os.path.exists(so_) and os.path.exists(qfile) and open(qfile).read().strip() == quick:
+        return so_
     if body == "ldsm":
         if fp_contract != "off":
             raise ValueError("body='ldsm' is a bit-exact back-end: fp_contract='off'")
@@ -1764,6 +1786,8 @@ def build_class(spec, fp_contract="fast", arch="gfx950", opt="-O3", block=64, fo
     digest = h.hexdigest()
     if (not force and os.path.exists(so) and os.path.exists(stamp)
             and open(stamp).read().strip() == digest):
+        with open(qfile, "w") as f:
+            f.write(quick)
         return so
     with open(hip, "w") as f:
         f.write(src)
@@ -1779,4 +1803,6 @@ def build_class(spec, fp_contract="fast", arch="gfx950", opt="-O3", block=64, fo
         raise RuntimeError(f"hipcc failed for class {cls}:\n{' '.join(cmd)}\n{r.stdout}\n{r.stderr}")
     with open(stamp, "w") as f:
         f.write(digest)
+    with open(qfile, "w") as f:
+        f.write(quick)
     return so

@@ -69,7 +69,7 @@ def test_oracle_reproduces_sls_trace(sls_spec, tape_oracle):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("which,tags", [("dcmotor", ["dcmotor_strict", "dcmotor_interp", "dcmotor_ldsm4"]),
+@pytest.mark.parametrize("which,tags", [("dcmotor", ["dcmotor_strict", "dcmotor_w32x", "dcmotor_interp", "dcmotor_ldsm4"]),
                                         ("l1l2", ["l1l2_interp", "l1l2_ldsm4"]),
                                         ("quadcopter", ["quadcopter_ldsm4"])])
 def test_gpu_reproduces_golden(which, tags):

@@ -358,9 +358,12 @@ def test_full_batch_properties(libs, variant):
     assert np.array_equal(it3, it[p]) and np.array_equal(x3, x[p])
 
 
-def test_dcmotor_strict_bit_exact_vs_oracle(libs, tmp_path):
+@pytest.mark.parametrize("tag", ["dcmotor_strict", "dcmotor_w32x"])
+def test_dcmotor_strict_bit_exact_vs_oracle(libs, tmp_path, tag):
     """BASELINE configs[3] problem (equality + inequality constraints, 323x323 KKT, second LDL for
-    initDualEqX__) through the generic one-thread-per-instance lowering: bit-identical to the oracle."""
+    initDualEqX__) through the generic one-thread-per-instance lowering and through the bit-exact wave-cooperative
+    one at 32 lanes per instance (two instances per wavefront, state in LDS shared by life time: the faster of the
+    two at one GPU's share of the sweep): bit-identical to the oracle."""
     import __graft_entry__ as g
     from tenscalc_amd.problems.mpc_dcmotor import SOLVE_ARGS as DC_ARGS, dcmotor_data, mpc_dcmotor
     from tenscalc_amd.tapeio import save_tape
@@ -370,7 +373,7 @@ def test_dcmotor_strict_bit_exact_vs_oracle(libs, tmp_path):
     save_tape(spec.tape, tape)
     B = 200
     data = [dcmotor_data(1000 + k) for k in range(B)]
-    obj = _load(libs["dcmotor_strict"], B)
+    obj = _load(libs[tag], B)
     names = [n for n, _ in spec.parameters + spec.variables]
     stacked = {n: np.stack([np.asarray(d[n], dtype=float).reshape(-1, order="F") for d in data]) for n in names}
     for n in names:
