@@ -17,10 +17,18 @@ spec = mpc_dcmotor(folder=g.GENERATED)
 if variant == "strict":
     so = spec.build(**g.VARIANT_KW["strict"])
 else:                                    # e.g. w64: 64 lanes share one instance, state in LDS
-    exact = variant.endswith("x")           # e.g. w32x: the bit-exact wave-cooperative lowering
+    base, _, extra = variant.partition("_")   # experiments: w32x_s8 (sched_every=8), w32x_inl (everything inlined)
+    exact = base.endswith("x")              # e.g. w32x: the bit-exact wave-cooperative lowering
     kw = dict(g.VARIANT_KW["w8x" if exact else "w8"])
-    share = variant.endswith("s") or exact  # e.g. w64s: LDS slots shared by life time
-    kw.update(lanes=int(variant[1:].rstrip("sx")), tag=variant, inline_max=32, share=share)
+    share = base.endswith("s") or exact     # e.g. w64s: LDS slots shared by life time
+    kw.update(lanes=int(base[1:].rstrip("sx")), tag=variant, inline_max=32, share=share)
+    for tok in [x for x in extra.split("-") if x]:     # e.g. w32x_inl-s8-fw12
+        if tok == "inl":
+            kw.update(inline_max=1000)
+        elif tok[0] == "s":
+            kw.update(sched_every=int(tok[1:]))
+        elif tok[:2] == "fw":
+            kw.update(fw_window=int(tok[2:]))
     so = spec.build(**kw)
 data = [dcmotor_data(k) for k in range(B)]
 names = [n for n, _ in spec.parameters + spec.variables]

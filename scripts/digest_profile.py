@@ -54,6 +54,7 @@ def main(out, rnd, var):
     t = json.load(open(tj)) if os.path.exists(tj) else {}
     if traffic is not None:
         B = {"quadcopter": 512, "l1l2": 16384, "dcmotor": 32768}.get(var.split("_")[0], 65536)
+        B = int(os.environ.get("TC_PROFILE_BATCH", "0")) or B
         t["%s_B%d" % (var, B)] = {"hbm_bytes_per_launch": traffic, "fetch_size_kib": pm["FETCH_SIZE"],
                                 "write_size_kib": pm["WRITE_SIZE"], "kernel_avg_ns": kavg, "round": rnd}
     json.dump(t, open(tj, "w"), indent=1)

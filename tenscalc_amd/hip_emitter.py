@@ -83,6 +83,10 @@ class Printer:
         # instead of through an LDS round trip the compiler cannot remove (it does not know that the
         # other lanes of the instance write other slots)
         self.forward = False
+        self.sched_every = 0        # a scheduling barrier after every sched_every single operands of a lane reduction
+        self.fw_window = 0          # forward a value only to the next fw_window units of its group (0: to all of them);
+        #                             in a 647-instruction LDL every early factor entry would otherwise stay live in a
+        #                             register to the end of the group -- 1 500 scratch accesses in mpc_dcmotor's
         self.branch_free_tails = True
         # exact=True (lanes>1): the wave-cooperative lowering keeps the reference's arithmetic bit for bit --
         # sums over lane-distributed operands are accumulated in the reference's term order (staged through LDS:
@@ -489,12 +493,17 @@ class Printer:
                 guard = "" if (q + 1) * L.P <= k1 - k0 else f"if (j_ < {k1 - k0}) "
                 body += f" {{ const int j_ = lane + {q * L.P}; {guard}{{ {step(cols)} }} }}"
         body += f" a_ = {red}(a_);"
-        for k in singles:
+        for q, k in enumerate(singles):
             cols = []
             for p in range(w):
                 kid = t.kids[k * w + p]
                 cols.append(self.leaf_text(kid) if isinstance(kid, Leaf) else "(" + self.expr(kid) + ")")
             body += " " + step(cols)
+            if self.sched_every and len(singles) > 2 * self.sched_every and q % self.sched_every == self.sched_every - 1:
+                # hundreds of operands outside any affine run (the rows of WW*dx - b in mpc_dcmotor's direction
+                # error): left alone the scheduler requests the LDS operands of ALL of them up front and spills
+                # (1 500 scratch accesses in that one group)
+                body += " __builtin_amdgcn_sched_barrier(0);"
         if self.exact:
             # min/max of the same operands is order independent EXCEPT where the reference's chain
             # "if (acc > x) acc = x" depends on position: a NaN operand (kept only in first position, skipped
@@ -779,7 +788,13 @@ class Printer:
                     cnt[lf.ins] = cnt.get(lf.ins, 0) + 1
             share = {j for j, c_ in cnt.items() if c_ >= 2}
         from .lowering import DFamily
-        for u in L.units[g - 1]:
+        born = {}
+        for uidx, u in enumerate(L.units[g - 1]):
+            if self.fw_window:
+                for key in [k_ for k_, b_ in born.items() if uidx - b_ > self.fw_window]:
+                    self._fw_rep.pop(key, None)
+                    self._fw_fam.pop(key, None)
+                    del born[key]
             if isinstance(u, DFamily):
                 out.append(self.dfamily_body(u))
                 continue
@@ -808,6 +823,7 @@ class Printer:
                                        f"MM((c_ < {u.n}) ? ({dst}) : TC_DUMMY) = {nm}_{k}; }} }}\n")
                     self._pending.append((u.dst0 + min(0, u.ddst * (u.n - 1)), u.dst0 + max(0, u.ddst * (u.n - 1))))
                     self._fw_fam[(u.dst0, u.ddst)] = (nm, u.n)
+                    born[(u.dst0, u.ddst)] = uidx
                 elif L.P > 1:
                     # the lanes sharing the instance split the members; LDS (in order within a
                     # wave) makes every element visible to all of them afterwards
@@ -835,6 +851,7 @@ class Printer:
                 if k_ in self._rv:
                     out.append(f"  c.rv[{self._rv[k_]}] = r{k_}_;\n")
                 self._fw_rep[k_] = f"r{k_}_"
+                born[k_] = uidx
             else:
                 out.append(f"  MM({L.pslot[i]}) = {e};\n")
         self._fw_rep, self._fw_fam = {}, {}
@@ -970,7 +987,7 @@ def _mask(groups):
 def emit_class(spec, fp_contract="fast", block=64, stats=False, roll=True, min_waves=0, lanes=1,
                recip=False, fast_div=False, inline_max=0, reg_budget=150, scratch="auto", body="code",
                waves=1, fuse=False, static_clean=False, forward=False, rcache=0, lds_state=0, share=False,
-               branch_free_tails=True, exact=False, stg_blocks=0, ilp=False):
+               branch_free_tails=True, exact=False, stg_blocks=0, ilp=False, fw_window=0, sched_every=0):
     """Return the HIP source text of the solver class.
 
     exact=True (lanes>1, fp_contract='off', no recip/fast_div): the wave-cooperative lowering with the
@@ -1020,6 +1037,8 @@ def emit_class(spec, fp_contract="fast", block=64, stats=False, roll=True, min_w
     P.forward = bool(forward) and lanes > 1
     P.exact = bool(exact) and lanes > 1
     P.ilp = bool(ilp)
+    P.fw_window = int(fw_window)
+    P.sched_every = int(sched_every)
     if P.exact and (recip or fast_div or fuse or fp_contract != "off"):
         raise ValueError("exact=True needs fp_contract='off' and no recip/fast_div/fuse")
     P.branch_free_tails = bool(branch_free_tails)
@@ -1729,7 +1748,7 @@ def build_class(spec, fp_contract="fast", arch="gfx950", opt="-O3", block=64, fo
                 outdir=None, stats=False, tag=None, extra_flags=(), roll=True, min_waves=0, lanes=1,
                 recip=False, fast_div=False, inline_max=0, reg_budget=150, scratch="auto", body="code",
                 waves=1, fuse=False, static_clean=False, forward=False, rcache=0, lds_state=0, share=False,
-                branch_free_tails=True, exact=False, stg_blocks=0, lds_slots=20000, ilp=False):
+                branch_free_tails=True, exact=False, stg_blocks=0, lds_slots=20000, ilp=False, fw_window=0, sched_every=0):
     """Emit <cls>.hip (+ <cls>.h, <cls>.tape) and compile lib<cls>.so with hipcc for gfx950.
     Mirrors the createGateway/compile step of cmex2optimizeCS.m:403-417."""
     from .tapeio import save_tape, tape_records, _rec
@@ -1746,7 +1765,7 @@ def build_class(spec, fp_contract="fast", arch="gfx950", opt="-O3", block=64, fo
     kq.update(repr((cls, sorted(spec.defines.items()), [(n, tuple(sz)) for n, sz in spec.outputs], fp_contract, arch, opt, block,
                     stats, tag, tuple(extra_flags), roll, min_waves, lanes, recip, fast_div, inline_max, reg_budget, scratch,
                     body, waves, fuse, static_clean, forward, rcache, lds_state, share, branch_free_tails, exact, stg_blocks,
-                    lds_slots, ilp, os.environ.get("TC_LDS_PAD_SLOTS", ""), os.environ.get("TC_SWEEP_UNROLL", ""))).encode())
+                    lds_slots, ilp, fw_window, sched_every, os.environ.get("TC_LDS_PAD_SLOTS", ""), os.environ.get("TC_SWEEP_UNROLL", ""))).encode())
     for f_ in sorted(os.listdir(HERE)):
         if f_.endswith(".py"):
             kq.update(open(os.path.join(HERE, f_), "rb").read())
@@ -1768,7 +1787,8 @@ def build_class(spec, fp_contract="fast", arch="gfx950", opt="-O3", block=64, fo
                         min_waves=min_waves, lanes=lanes, recip=recip, fast_div=fast_div, inline_max=inline_max,
                         reg_budget=reg_budget, scratch=scratch, body=body, waves=waves, fuse=fuse,
                         static_clean=static_clean, forward=forward, rcache=rcache, lds_state=lds_state,
-                        share=share, branch_free_tails=branch_free_tails, exact=exact, stg_blocks=stg_blocks, ilp=ilp)
+                        share=share, branch_free_tails=branch_free_tails, exact=exact, stg_blocks=stg_blocks, ilp=ilp,
+                        fw_window=fw_window, sched_every=sched_every)
     hip = os.path.join(outdir, f"{cls}{suffix}.hip")
     so = os.path.join(outdir, f"lib{cls}{suffix}.so")
     flags = [opt, f"--offload-arch={arch}", "-fPIC", "-shared", "-std=c++17",
