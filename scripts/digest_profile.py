@@ -13,7 +13,9 @@ def main(out, rnd, var):
     dst = os.path.join(root, "gpurun_out", "profiles_%s" % rnd)
     os.makedirs(dst, exist_ok=True)
     cmdline = ("--steps 20 --warmup 3 --no-cpu --variant %s" % var) if "_" not in var else \
-        ("--config %s --variant %s --steps 3 --warmup 1 --no-cpu" % tuple(var.split("_", 1)))
+        ("--config %s --variant %s%s --steps %s --warmup 1 --no-cpu" % (tuple(var.split("_", 1)) + (
+            (" --batch " + os.environ["TC_PROFILE_BATCH"]) if int(os.environ.get("TC_PROFILE_BATCH", "0")) else "",
+            os.environ.get("TC_PROFILE_STEPS", "3"))))
     lines = ["rocprofv3 --kernel-trace --stats summary of: python3 bench.py " + cmdline,
              "Name,Calls,TotalDurationNs,AverageNs,Percentage,MinNs,MaxNs,StdDev"]
     kavg = None

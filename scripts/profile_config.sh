@@ -9,4 +9,4 @@ cd /tmp && export TMPDIR=/tmp
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/kt -- python3 $R/bench.py --config $CFG --variant $VAR --batch $BATCH --steps $STEPS --warmup 1 --no-cpu > $OUT/kt.log 2>&1
 rocprofv3 --pmc FETCH_SIZE --output-format csv -d $OUT/pmc_fetch -- python3 $R/bench.py --config $CFG --variant $VAR --batch $BATCH --steps 2 --warmup 1 --no-cpu > $OUT/pmc_fetch.log 2>&1
 rocprofv3 --pmc WRITE_SIZE --output-format csv -d $OUT/pmc_write -- python3 $R/bench.py --config $CFG --variant $VAR --batch $BATCH --steps 2 --warmup 1 --no-cpu > $OUT/pmc_write.log 2>&1
-cd $R && TC_PROFILE_BATCH=$BATCH python3 scripts/digest_profile.py $OUT $ROUND ${CFG}_${VAR}
+cd $R && TC_PROFILE_BATCH=$BATCH TC_PROFILE_STEPS=$STEPS python3 scripts/digest_profile.py $OUT $ROUND ${CFG}_${VAR}
