@@ -26,8 +26,9 @@
  * caller's stream (NULL = the handle's): work enqueued there is ordered AFTER everything the handle's stream
  * already holds and BEFORE anything enqueued later on the handle's stream (an event links the two), so
  * tc_solve_async(h,...,s) followed by tc_get_outputs(h,...) reads finished results, and a tc_set cannot
- * overwrite inputs a solve on another stream is still reading.  Two DIFFERENT caller streams are not ordered
- * with respect to each other by the library.
+ * overwrite inputs a solve on another stream is still reading.  Two DIFFERENT caller streams used on one handle
+ * are chained the same way, in call order: an entry point given stream B first joins what an earlier call left in
+ * flight on stream A into the handle's stream, then orders B behind it.
  */
 #ifndef TENSCALC_HIP_H
 #define TENSCALC_HIP_H

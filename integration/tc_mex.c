@@ -1,9 +1,14 @@
 /* Generic MATLAB mex gateway onto a TensCalc-HIP class library (include/tenscalc_hip.h).
  *
- * UNVERIFIED: this image has no MATLAB (no mex.h), so this file has never been compiled.  It is
- * the binding a TensCalc maintainer adds next to the gateways that CmexTools' createGateway
+ * It is the binding a TensCalc maintainer adds next to the gateways that CmexTools' createGateway
  * generates today (lib/cmex2optimizeCS.m:403-417); the dlopen/dlsym pattern is the reference's
  * own (lib/csparse/instructionsTableHeight4MEX.c:40-54).
+ *
+ * Status: this image has no MATLAB, so the file has never been compiled against MathWorks' mex.h.  It IS
+ * compiled and driven end to end against a small stand-in for the mex API (tests/mock_mex/: the dozen mx* / mex*
+ * calls used below, errors delivered by longjmp as mexErrMsgIdAndTxt does) -- argument validation and handle life
+ * cycle on the CPU, a create / set / solve / get / destroy round trip against the golden vectors on the GPU
+ * (tests/test_mex_gateway.py).
  *
  *   h   = tc_mex('create', libpath, B)            % obj=<cls>()
  *         tc_mex('set', h, name, value)           % setP_<name>/setV_<name>: value is [size...,B]
@@ -11,7 +16,11 @@
  *   [y1,y2,...] = tc_mex('get', h)                % getOutputs: each [size...,B]
  *         tc_mex('destroy', h)
  *
- * Build (on a machine with MATLAB + ROCm):  mex tc_mex.c -ldl
+ * Handles are (slot, generation) pairs into a table of live objects kept by this mex file, never raw pointers:
+ * a stale or made-up handle is an error message, not a use-after-free; whatever is still alive when MATLAB clears
+ * the mex file is destroyed by the mexAtExit hook.
+ *
+ * Build (on a machine with MATLAB + ROCm):  mex -I<repo>/include tc_mex.c -ldl
  */
 #include <dlfcn.h>
 #include <stdint.h>
@@ -23,6 +32,7 @@ typedef struct {
   void *lib;
   tc_solver_t *h;
   int64_t B;
+  uint32_t generation;        /* bumped at every create in this slot: handles of earlier occupants do not match */
   int (*create)(int64_t, int, tc_solver_t **);
   int (*destroy)(tc_solver_t *);
   int (*set)(tc_solver_t *, const char *, const double *, int64_t);
@@ -37,6 +47,21 @@ typedef struct {
   int64_t (*inumel)(int);
   const char *(*err)(void);
 } obj_t;
+
+#define TCM_MAX 64
+static obj_t tcm_objs[TCM_MAX];       /* static storage: nothing to leak, nothing MATLAB's allocator can take away */
+static int tcm_atexit_set = 0;
+
+static void tcm_release(obj_t *o) {
+  if (o->h) o->destroy(o->h);
+  o->h = NULL;
+  if (o->lib) dlclose(o->lib);
+  o->lib = NULL;
+}
+
+static void tcm_at_exit(void) {
+  for (int k = 0; k < TCM_MAX; k++) tcm_release(&tcm_objs[k]);
+}
 
 static void need(int ok, const char *msg) {
   if (!ok) mexErrMsgIdAndTxt("tenscalc:hip", "tc_mex: %s", msg);
@@ -55,8 +80,18 @@ void mexFunction(int nlhs, mxArray *plhs[], int nrhs, const mxArray *prhs[]) {
          "create: (libpath, B) expected");
     need(!mxGetString(prhs[1], path, sizeof path), "create: library path too long");
     need(mxGetScalar(prhs[2]) >= 1, "create: B must be >= 1");
-    obj_t *o = (obj_t *)mxCalloc(1, sizeof *o);
-    mexMakeMemoryPersistent(o);
+    int slot = -1;
+    for (int k = 0; k < TCM_MAX && slot < 0; k++)
+      if (!tcm_objs[k].lib) slot = k;
+    need(slot >= 0, "create: too many live solver objects (64)");
+    if (!tcm_atexit_set) {
+      mexAtExit(tcm_at_exit);
+      tcm_atexit_set = 1;
+    }
+    obj_t *o = &tcm_objs[slot];
+    const uint32_t gen = o->generation + 1;
+    memset(o, 0, sizeof *o);
+    o->generation = gen;
     o->lib = dlopen(path, RTLD_NOW | RTLD_LOCAL);
     if (!o->lib) mexErrMsgIdAndTxt("tenscalc:hip", "cannot load %s: %s", path, dlerror());
     *(void **)&o->create = dlsym(o->lib, "tc_create");
@@ -72,17 +107,32 @@ void mexFunction(int nlhs, mxArray *plhs[], int nrhs, const mxArray *prhs[]) {
     *(void **)&o->inumel = dlsym(o->lib, "tc_input_numel");
     *(void **)&o->err = dlsym(o->lib, "tc_last_error");
     if (!o->create || !o->destroy || !o->set || !o->solve || !o->get || !o->nout || !o->ondim || !o->odim ||
-        !o->nin || !o->iname || !o->inumel || !o->err)
+        !o->nin || !o->iname || !o->inumel || !o->err) {
+      dlclose(o->lib);      /* the slot is free again before the error unwinds */
+      o->lib = NULL;
       mexErrMsgIdAndTxt("tenscalc:hip", "%s is not a TensCalc-HIP class library (missing tc_* symbols)", path);
+    }
     o->B = (int64_t)mxGetScalar(prhs[2]);
-    check(o, o->create(o->B, 0, &o->h), "tc_create");
+    int rc = o->create(o->B, 0, &o->h);
+    if (rc) {
+      char msg[512];
+      strncpy(msg, o->err(), sizeof msg - 1);
+      msg[sizeof msg - 1] = 0;
+      o->h = NULL;
+      dlclose(o->lib);
+      o->lib = NULL;
+      mexErrMsgIdAndTxt("tenscalc:hip", "tc_create failed (%d): %s", rc, msg);
+    }
     plhs[0] = mxCreateNumericMatrix(1, 1, mxUINT64_CLASS, mxREAL);
-    *(uint64_t *)mxGetData(plhs[0]) = (uint64_t)(uintptr_t)o;
+    *(uint64_t *)mxGetData(plhs[0]) = ((uint64_t)o->generation << 32) | (uint64_t)(slot + 1);
     return;
   }
   need(nrhs >= 2 && mxIsUint64(prhs[1]) && mxGetNumberOfElements(prhs[1]) == 1, "handle (uint64 scalar) expected");
-  obj_t *o = (obj_t *)(uintptr_t)(*(uint64_t *)mxGetData(prhs[1]));
-  need(o != NULL && o->h != NULL, "handle already destroyed");
+  const uint64_t hv = *(uint64_t *)mxGetData(prhs[1]);
+  const uint64_t slot1 = hv & 0xffffffffu;
+  need(slot1 >= 1 && slot1 <= TCM_MAX, "not a handle returned by tc_mex('create', ...)");
+  obj_t *o = &tcm_objs[slot1 - 1];
+  need(o->lib != NULL && o->h != NULL && o->generation == (uint32_t)(hv >> 32), "handle already destroyed");
   if (!strcmp(cmd, "set")) {
     char name[256];
     need(nrhs == 4 && mxIsChar(prhs[2]), "set: (h, name, value) expected");
@@ -119,6 +169,7 @@ void mexFunction(int nlhs, mxArray *plhs[], int nrhs, const mxArray *prhs[]) {
     for (int k = 0; k < n; k++) {
       mwSize dims[9];
       int nd = o->ondim(k);
+      need(nd >= 0 && nd <= 8, "get: output with more than 8 dimensions");
       for (int d = 0; d < nd; d++) dims[d] = (mwSize)o->odim(k, d);
       dims[nd] = (mwSize)o->B;
       mxArray *a = mxCreateNumericArray(nd + 1, dims, mxDOUBLE_CLASS, mxREAL);
@@ -129,10 +180,7 @@ void mexFunction(int nlhs, mxArray *plhs[], int nrhs, const mxArray *prhs[]) {
     mxFree(ptr);
     check(o, rc, "tc_get_outputs");
   } else if (!strcmp(cmd, "destroy")) {
-    o->destroy(o->h);
-    o->h = NULL;
-    dlclose(o->lib);
-    mxFree(o);
+    tcm_release(o);        /* the slot's generation stays: this handle value never matches again */
   } else {
     mexErrMsgIdAndTxt("tenscalc:hip", "unknown command %s", cmd);
   }

@@ -25,7 +25,7 @@ from . import instructions as I
 from . import tcalculus as tc
 from .instructions import InstructionsTable
 
-__all__ = ["CSparse", "Tape", "min_degree_order"]
+__all__ = ["CSparse", "Tape", "min_degree_order", "multiple_elimination_order", "depth_aware_order", "symbolic_ldl_cost"]
 
 
 # ----------------------------------------------------------------------------------
@@ -83,6 +83,10 @@ def _groups(sorted_keys):
 
 
 LDL_GATE = "one"     # how `stages` constrains the elimination order (see min_degree_order)
+# which elimination order `ldl` nodes get: "mindeg" = greedy minimum degree (fill first; stands in for symamd), or
+# ("depth", width) = depth_aware_order: the shortest critical path that `width` parallel lanes can pay for in fill.
+# CSparse.ldl_order overrides it per generated class (cmex2optimizeCS(..., ldlOrder=...)).
+LDL_ORDER = "mindeg"
 
 
 def min_degree_order(n, rows, cols, stages=None, gate=None):
@@ -109,7 +113,7 @@ def min_degree_order(n, rows, cols, stages=None, gate=None):
             adj[r].add(c)
             adj[c].add(r)
     import heapq
-    stg = [0] * n if stages is None else [int(s) for s in stages]
+    stg = [0] * n if stages is None else [int(s) if int(s) != 2 else 0 for s in stages]    # 2: see multiple_elimination_order
     if gate == "stage":
         key = stg
         need = [0] * n
@@ -158,6 +162,147 @@ def min_degree_order(n, rows, cols, stages=None, gate=None):
     return np.array(order, dtype=np.int64)
 
 
+def _gate_one(n, adj, stages):
+    """(need, gated_by): how many eliminations a node waits for, and who is told when a node goes.  Stage 1 (equality
+    duals, own diagonal -addEye2HessianEq) waits for ONE eliminated stage-0 neighbour, the gate "one" of
+    min_degree_order.  Stage 2 marks the inequality duals (own diagonal -F*lambda): a stage-0 node waits for ALL its
+    stage-2 neighbours, so that a primal variable whose only curvature is the barrier term lambda/F (a slack, a
+    norm's flat direction) never becomes a pivot of size addEye2HessianU before it has received that term."""
+    stg = [0] * n if stages is None else [int(s) for s in stages]
+    need = [0] * n
+    gated_by = [[] for _ in range(n)]
+    for i in range(n):
+        if stg[i] == 1:
+            early = [a for a in adj[i] if stg[a] == 0]
+            need[i] = min(1, len(early))
+        elif stg[i] == 0:
+            early = [a for a in adj[i] if stg[a] == 2]
+            need[i] = len(early)
+        else:
+            early = []
+        for a in early:
+            gated_by[a].append(i)
+    return need, gated_by
+
+
+def multiple_elimination_order(n, rows, cols, stages=None, slack=0):
+    """Elimination order built in ROUNDS: every round eliminates a maximal independent set of the eligible nodes whose
+    degree is within ``slack`` of the current minimum (Liu's multiple minimum degree, with a tolerance).  Nodes of one
+    round do not depend on each other, so the elimination tree gets short and bushy: a tridiagonal block is reduced
+    odd-even (cyclic reduction, depth log n) instead of front to back (depth n).  Fill grows with ``slack``.
+    Late nodes (``stages``) obey the gate "one" of :func:`min_degree_order`."""
+    adj = [set() for _ in range(n)]
+    for r, c in zip(rows, cols):
+        r, c = int(r), int(c)
+        if r != c:
+            adj[r].add(c)
+            adj[c].add(r)
+    need, gated_by = _gate_one(n, adj, stages)
+    seen = [0] * n
+    done = [False] * n
+    order = []
+    while len(order) < n:
+        elig = [i for i in range(n) if not done[i] and seen[i] >= need[i]]
+        if not elig:
+            raise AssertionError("multiple_elimination_order: gated nodes left over")
+        dmin = min(len(adj[i]) for i in elig)
+        blocked = set()
+        chosen = []
+        for d, i in sorted((len(adj[i]), i) for i in elig if len(adj[i]) <= dmin + slack):
+            if i not in blocked:
+                chosen.append(i)
+                blocked.add(i)
+                blocked |= adj[i]
+        for i in chosen:
+            done[i] = True
+            order.append(i)
+            nb = adj[i]
+            for a in nb:
+                adj[a].discard(i)
+            for a in list(nb):
+                new = nb - adj[a]
+                new.discard(a)
+                if new:
+                    adj[a] |= new
+            for a in gated_by[i]:
+                seen[a] += 1
+            adj[i] = set()
+    return np.array(order, dtype=np.int64)
+
+
+def symbolic_ldl_cost(n, rows, cols, p, term_weight=1.0 / 16):
+    """What the up-looking LDL' of sparsity_ldl.m:161-222 and the two triangular solves cost under the order ``p``:
+    nnz(L), multiply-adds, and the length of the longest dependency chain through factorisation + forward + backward
+    substitution, an instruction with t terms counting 1 + t*term_weight (its ordered sum is a chain of its own)."""
+    pinv = np.empty(n, dtype=np.int64)
+    pinv[np.asarray(p)] = np.arange(n)
+    acol = [set() for _ in range(n)]            # permuted strictly-lower structure of A by column
+    for r, c in zip(rows, cols):
+        pr, pc = int(pinv[int(r)]), int(pinv[int(c)])
+        if pr > pc:
+            acol[pc].add(pr)
+        elif pc > pr:
+            acol[pr].add(pc)
+    Lrow = [dict() for _ in range(n)]           # row -> {col: finish time of L(row, col)}
+    Lcol = [[] for _ in range(n)]
+    tD = [0.0] * n
+    flops = 0
+    for col in range(n):
+        Lr = Lrow[col]
+        iss = sorted(Lr)
+        t0 = 0.0
+        for i in iss:
+            t0 = max(t0, Lr[i], tD[i])
+        tD[col] = t0 + 1 + len(iss) * term_weight if iss else 0.0
+        flops += 2 * len(iss)
+        cand = set(acol[col])
+        for i in iss:
+            cand.update(r for r in Lcol[i] if r > col)
+        for row in sorted(cand):
+            Lrr = Lrow[row]
+            isr = [i for i in iss if i in Lrr]
+            t1 = tD[col]
+            for i in isr:
+                t1 = max(t1, Lrr[i], Lr[i], tD[i])
+            Lrr[col] = t1 + 1 + len(isr) * term_weight
+            Lcol[col].append(row)
+            flops += 2 * len(isr) + 1
+    depth = max(max(tD), max((max(d.values()) for d in Lrow if d), default=0.0))
+    y = [0.0] * n
+    for r in range(n):
+        if Lrow[r]:
+            y[r] = max(y[k] for k in Lrow[r]) + 1 + len(Lrow[r]) * term_weight
+    x = [0.0] * n
+    for r in range(n - 1, -1, -1):
+        if Lcol[r]:
+            x[r] = max(x[k] for k in Lcol[r]) + 1 + len(Lcol[r]) * term_weight
+    flops += 4 * sum(len(d) for d in Lrow)
+    return dict(nnzL=sum(len(d) for d in Lrow), flops=flops, depth=depth + max(y) + max(x))
+
+
+def depth_aware_order(n, rows, cols, stages=None, width=64):
+    """The elimination order for a machine that is wide but slow per dependent step: among the greedy minimum-degree
+    order and multiple-elimination orders of growing tolerance, the one with the smallest
+    ``critical path + multiply-adds / width`` (:func:`symbolic_ldl_cost`).  ``width`` = how many scalar
+    instructions of one instance the back-end executes side by side.
+
+    With equality duals (stage 1) in the matrix only tolerance 0 is tried: their pivots are the bare
+    -addEye2HessianEq until a neighbour has been eliminated, and which neighbour comes first decides how many digits
+    survive -- measured on mpc_quadcopter's and mpc_dcmotor's KKT matrices, tolerance >= 1 (quadcopter) or >= 2
+    (dcmotor) turns a direction error of 1e-9 / 1e-16 into 1e-1 / 1e-8.  Without equality constraints
+    (l1l2) every order tried is as accurate as the greedy one."""
+    has_eq = stages is not None and any(int(s) == 1 for s in stages)
+    best = None
+    for slack in ((None, 0) if has_eq else (None, 0, 1, 2, 3, 4, 6, 8, 12)):
+        p = (min_degree_order(n, rows, cols, stages, "one") if slack is None
+             else multiple_elimination_order(n, rows, cols, stages, slack))
+        c = symbolic_ldl_cost(n, rows, cols, p)
+        score = c["depth"] + c["flops"] / float(width)
+        if best is None or score < best[0]:
+            best = (score, p, slack, c)
+    return best[1]
+
+
 class CSparse:
     def __init__(self):
         self.table = InstructionsTable()
@@ -166,6 +311,7 @@ class CSparse:
         self.load_value = {}       # instruction id -> constant (I_load)
         self.sets, self.gets, self.copies = [], [], []
         self.ldl_perm = {}         # ldl node idx -> permutation (0-based)
+        self.ldl_order = None      # None -> module attribute LDL_ORDER
         self.ldl_stats = []
         self._one = None
 
@@ -634,7 +780,15 @@ class CSparse:
         ent = {(int(r), int(c)): int(i) for (r, c), i in zip(subs, ins)}
         nonsym = sum(1 for (r, c), i in ent.items() if ent.get((c, r)) != i)
         tag, stages = n.par
-        p = min_degree_order(N, subs[:, 0], subs[:, 1], stages)
+        how = self.ldl_order or LDL_ORDER
+        if how == "mindeg":
+            p = min_degree_order(N, subs[:, 0], subs[:, 1], stages)
+        elif isinstance(how, (tuple, list)) and how[0] == "depth":
+            p = depth_aware_order(N, subs[:, 0], subs[:, 1], stages, width=int(how[1]))
+        elif isinstance(how, (tuple, list)) and how[0] == "mmd":
+            p = multiple_elimination_order(N, subs[:, 0], subs[:, 1], stages, slack=int(how[1]))
+        else:
+            raise ValueError("ldl order: 'mindeg', ('depth', width) or ('mmd', slack)")
         pinv = np.empty(N, dtype=np.int64)
         pinv[p] = np.arange(N)
         # permuted lower triangle (row>col) and diagonal: Xp(r,c)=A(p[r],p[c])

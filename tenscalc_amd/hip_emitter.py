@@ -1057,7 +1057,10 @@ def emit_class(spec, fp_contract="fast", block=64, stats=False, roll=True, min_w
     lb = f"__launch_bounds__(TC_BLOCK, {int(min_waves)})" if min_waves else "__launch_bounds__(TC_BLOCK)"
     w.append(f"#define TC_LAUNCH_BOUNDS {lb}\n")
     if stats:       # stats="phases": only the per-phase counters of the Newton loop (8 registers; the per-group
-        w.append("#define TC_STATS %d\n" % (2 if stats == "phases" else 1))     # arrays perturb register allocation)
+        # stats="trace": lane 0 of block 0 writes (tag, s_memtime) pairs to the dbg buffer at every group evaluation and
+        # phase boundary (one pointer in registers: the least perturbing of the three)
+        w.append("#define TC_STATS %d\n" % {"phases": 2, "trace": 3}.get(stats, 1))     # arrays perturb register allocation)
+        w.append("#define TC_TRACE_BLOCK %d\n" % int(os.environ.get("TC_TRACE_BLOCK", "0")))
     w.append("// solver configuration (reference: cmex2optimizeCS.m:303-331)\n")
     for k in ["nU", "nG", "nF", "scaleCost", "scaleInequalities", "scaleEqualities", "coupledAlphas",
               "setAddEye2Hessian", "adjustAddEye2Hessian", "useInertia", "delta", "skipAffine",
@@ -1133,7 +1136,8 @@ def emit_class(spec, fp_contract="fast", block=64, stats=False, roll=True, min_w
              "struct TcCtx {\n  tc_mem m;\n  tc_lds ls;\n  tc_glob S;\n  tc_glob Sd;\n  long B, sdB;\n  int lane;\n"
              "  const __attribute__((address_space(1))) char *Sdb;\n  unsigned sdo8, sdB8;\n"
              "  unsigned long long st[TC_NSTW];\n" + (f"  double rv[{nrv}];\n" if nrv else "") + dmembers +
-             "#ifdef TC_STATS\n  int nMinF;\n  long long cyc[TC_NGROUPS];\n  int cnt[TC_NGROUPS];\n  long long ph[8], tph;\n#endif\n};\n"
+             "#if defined(TC_STATS) && TC_STATS == 3\n  __attribute__((address_space(1))) double *trp;\n"
+             "#elif defined(TC_STATS)\n  int nMinF;\n  long long cyc[TC_NGROUPS];\n  int cnt[TC_NGROUPS];\n  long long ph[8], tph;\n#endif\n};\n"
              # input reads are clamped to the input block: every index the emitter prints is in range (constants
              # fold away), the clamp is the backstop for a lane of a split loop that should have been masked
              "#define SX(k) (S[(long)((k) < TC_NEXT ? (k) : (TC_NEXT > 0 ? TC_NEXT - 1 : 0)) * B])\n"
@@ -1193,7 +1197,13 @@ def emit_class(spec, fp_contract="fast", block=64, stats=False, roll=True, min_w
             w.append(f"}}\n#define TC_CALL_GRP{g} tc_grp{g}(c.m, c.S, c.B, c.lane)\n")
     w.append("\n// TC_EVAL: the group is certainly dirty here (loop_schedule.py): evaluate without testing the flag\n"
              "#define TC_EVAL(g) do { c.st[((g)-1)>>6] |= 1ull << (((g)-1)&63); TC_CALL_GRP##g; } while (0)\n")
-    w.append("\n#if !defined(TC_STATS) || TC_STATS == 2\n#define TC_NEED(g) do { if (!((c.st[((g)-1)>>6] >> (((g)-1)&63)) & 1ull)) { "
+    w.append("\n#if defined(TC_STATS) && TC_STATS == 3\n"
+             "#define TC_STAMP(tag) do { if (c.trp) { c.trp[0] = (double)(tag); c.trp[1] = (double)clock64(); c.trp += 2; } } while (0)\n"
+             "#undef TC_EVAL\n"
+             "#define TC_EVAL(g) do { c.st[((g)-1)>>6] |= 1ull << (((g)-1)&63); TC_STAMP(g); TC_CALL_GRP##g; TC_STAMP(-(g)); } while (0)\n"
+             "#define TC_NEED(g) do { if (!((c.st[((g)-1)>>6] >> (((g)-1)&63)) & 1ull)) { "
+             "c.st[((g)-1)>>6] |= 1ull << (((g)-1)&63); TC_STAMP(g); TC_CALL_GRP##g; TC_STAMP(-(g)); } } while (0)\n"
+             "#elif !defined(TC_STATS) || TC_STATS == 2\n#define TC_NEED(g) do { if (!((c.st[((g)-1)>>6] >> (((g)-1)&63)) & 1ull)) { "
              "c.st[((g)-1)>>6] |= 1ull << (((g)-1)&63); TC_CALL_GRP##g; } } while (0)\n"
              "#else  // diagnostic build: wall cycles (s_memtime) and call count per dependency group\n"
              "#define TC_NEED(g) do { if (!((c.st[((g)-1)>>6] >> (((g)-1)&63)) & 1ull)) { "
@@ -1366,7 +1376,10 @@ def emit_class(spec, fp_contract="fast", block=64, stats=False, roll=True, min_w
                 "  c.m = (tc_lds)&tc_lds_m[(threadIdx.x / TC_P) * TC_NMP];\n#endif\n"
                 "  c.lane = (int)(t_ % TC_P);\n  c.S = (tc_glob)(S + tid);\n  c.B = B;\n"
                 "  for (int k = 0; k < TC_NSTW; k++) c.st[k] = 0;\n"
-                "#ifdef TC_STATS\n  c.nMinF = 0;\n  for (int k = 0; k < TC_NGROUPS; k++) { c.cyc[k] = 0; c.cnt[k] = 0; }\n"
+                "#if defined(TC_STATS) && TC_STATS == 3\n"
+                "  c.trp = (dbg && blockIdx.x == TC_TRACE_BLOCK && threadIdx.x == 0) ? (__attribute__((address_space(1))) double *)dbg : nullptr;\n"
+                "  if (c.trp) { c.trp[0] = 1000.0; c.trp[1] = (double)clock64(); c.trp += 2; }\n"
+                "#elif defined(TC_STATS)\n  c.nMinF = 0;\n  for (int k = 0; k < TC_NGROUPS; k++) { c.cyc[k] = 0; c.cnt[k] = 0; }\n"
                 "  for (int k = 0; k < 8; k++) c.ph[k] = 0;\n"
                 "  const long long tstart_ = clock64();\n  c.tph = tstart_;\n#endif\n")
     prologue += ("  c.Sd = (tc_glob)(Sd + tid * TC_P + c.lane);\n  c.sdB = B * TC_P;\n"
@@ -1422,7 +1435,8 @@ def emit_class(spec, fp_contract="fast", block=64, stats=False, roll=True, min_w
             out_meta.append((o["name"], o["size"], n_, off))
             off += n_
     w.append("  status[tid] = st;\n  iter[tid] = it;\n"
-             "#ifdef TC_STATS\n  if (dbg) {\n    for (int k = 0; k < TC_NGROUPS; k++) {\n"
+             "#if defined(TC_STATS) && TC_STATS == 3\n  if (c.trp) { c.trp[0] = 1001.0; c.trp[1] = (double)clock64(); c.trp[2] = 0.0; }\n"
+             "#elif defined(TC_STATS)\n  if (dbg) {\n    for (int k = 0; k < TC_NGROUPS; k++) {\n"
              "      dbg[(long)k * B + tid] = (double)c.cyc[k];\n      dbg[(long)(TC_NGROUPS + k) * B + tid] = (double)c.cnt[k];\n    }\n"
              "    dbg[(long)(2 * TC_NGROUPS) * B + tid] = (double)(clock64() - tstart_);\n"
              "    dbg[(long)(2 * TC_NGROUPS + 1) * B + tid] = (double)c.nMinF;\n"
@@ -1430,7 +1444,8 @@ def emit_class(spec, fp_contract="fast", block=64, stats=False, roll=True, min_w
     # probe kernel: init sequence then one get
     w.append("extern \"C\" __global__ void __launch_bounds__(TC_BLOCK)\n"
              "tc_probe_kernel(const double *__restrict__ S, const double *__restrict__ Sd, double *__restrict__ out,\n"
-             "                int which, double mu0, double ae0, double ae1, long B, double *__restrict__ Mg) {\n" + prologue +
+             "                int which, double mu0, double ae0, double ae1, long B, double *__restrict__ Mg) {\n"
+             "#if defined(TC_STATS) && TC_STATS == 3\n  double *dbg = nullptr;\n#endif\n" + prologue +
              "#if setAddEye2Hessian != 0\n  setAddEye2HessianU__(c, &ae0);\n  setAddEye2HessianEq__(c, &ae1);\n#endif\n"
              f"  initPrimal__{full}(c);\n"
              f"#if scaleCost != 0\n  scaleCost__{full}(c);\n#endif\n"

@@ -127,7 +127,7 @@ def ipmPD_CStimesLambda(code, u, f, F, G, lam, nu, *, addEye2Hessian=True, scale
     out["Hess"] = WW
     # elimination order: fill-reducing within {primal, inequality duals}, equality duals last so
     # their -addEye2HessianEq pivots are never used before the primal block they couple
-    factor_ww = ldl(WW, classname + "_WW", stages=[0] * nU + [1] * nG + [0] * nF)
+    factor_ww = ldl(WW, classname + "_WW", stages=[0] * nU + [1] * nG + [2] * nF)
     out["dHess"] = ldl_d(factor_ww)
     out["lHess"] = ldl_l(factor_ww)
     code.declareGet([tsum(compose(out["dHess"], "heaviside")),
@@ -296,7 +296,7 @@ def ipmPD_CS(code, u, f, F, G, lam, nu, *, addEye2Hessian=True, scaleCost=0.0, s
                 rows[1].append(Tzeros((nG, nF)))
             rows[2] = [-F_u] + ([Tzeros((nF, nG))] if nG > 0 else []) + [-diag(rdivide(F, lam))]
         WW = blocks(rows)
-        factor_ww = ldl(WW, classname + "_WW", stages=[0] * nU + [1] * nG + [0] * nF)
+        factor_ww = ldl(WW, classname + "_WW", stages=[0] * nU + [1] * nG + [2] * nF)
         mid = [-G] if nG > 0 else []
         if skipAffine or nF == 0:
             b_s = cat(1, -Lf_u, *mid, *([F - rdivide(muOnes, lam)] if nF > 0 else []))
@@ -347,7 +347,7 @@ def ipmPD_CS(code, u, f, F, G, lam, nu, *, addEye2Hessian=True, scaleCost=0.0, s
             out["Hess1"] = WW[rest, rest]
             out["B1"] = -WW[rest, s1]
             nr = int((~isSensitivity).sum())
-            factor_Hess1 = ldl(out["Hess1"], classname + "_Hess1", stages=[0] * nr + [1] * nG + [0] * nF)
+            factor_Hess1 = ldl(out["Hess1"], classname + "_Hess1", stages=[0] * nr + [1] * nG + [2] * nF)
             out["Du1"] = mldivide(factor_Hess1, out["B1"])
             D2 = D2 + WW[s1, rest] * out["Du1"]
         else:

@@ -718,16 +718,79 @@ def class_stream(T, classname, defines, W=1, lds_slots=20000, hoist=True, nested
         raise AssertionError("output without storage")
     out_off = len(words)
     words += out_addr + [0] * (-len(out_addr) % 8)
-    validate(words, headers, table, W, nLds, nLds + sl["nGlob"])
+    unwalked = {rid[g] for g in getattr(sl["lowering"], "dead_groups", ()) if g in rid}
+    validate(words, headers, table, W, nLds, nLds + sl["nGlob"], dummy=sl["dummy"], unwalked=unwalked)
     return dict(sl, words=words, headers=headers, rid=rid, table=table, out_off=out_off, nOut=len(out_addr),
                 gstats=st["gstats"], W=W)
 
 
-def validate(words, headers, table, W, nLds, nAddr):
+def record_accesses(words, hdr):
+    """(addresses read, addresses written) by the active lanes of one record -- the device walk's semantics, as the
+    CPU model of tests/test_ldsm_stream.py restates them"""
+    w0, n, aux, cnt, off, flags, cn, _ = (int(x) for x in hdr)
+    kind, op = w0 >> 8, w0 & 255
+    body = record_body(words, hdr)
+    rd, wr = set(), set(int(x) for x in body[0][:cnt])
+    if kind == K_SHORT:
+        for j in range(n):
+            rd.update(int(x) >> 1 for x in body[1 + j][:cnt])
+    elif kind == K_FOLD:
+        nlm = (flags >> F_NLATE_SHIFT) & 3
+        for q in range(cnt):
+            ln, base = int(body[1][q]), int(body[4][q])
+            nrow = -(-ln // 8) * 8 if flags & F_PADDED else ln
+            rd.update(range(base, base + nrow))
+            rd.add(int(body[2][q]) >> 1)
+            rd.add(int(body[3][q]) >> 1)
+            if nlm:
+                for t in range(int(body[5][q])):
+                    wr.add(base + int(body[6 + 4 * t][q]))
+                    rd.update(int(body[7 + 4 * t + j][q]) >> 1 for j in range(3))
+    else:
+        skip = _DOT_SKIP.get(op, 0)
+        for q in range(cnt):
+            rd.update(int(body[2 + j][q]) >> 1 for j in range(skip))
+            rd.update(int(body[4 + k][q]) >> 1 for k in range(int(body[1][q])))
+    return rd, wr
+
+
+def validate(words, headers, table, W, nLds, nAddr, dummy=None, unwalked=()):
     """every address a lane would touch is inside [0, nAddr); ranges end on header boundaries; the waves sharing a
-    range meet the same number of barriers"""
+    range meet the same number of barriers; and within one step (barrier to barrier) no wave writes an address that
+    ANOTHER wave of the range reads or writes in the same step -- on the device the waves of a step run side by
+    side, so such a pair would be a race whatever order a sequential model happens to take (`dummy`: the slot the
+    masked lanes of ragged records write to, never read for its value; `unwalked`: ranges of groups that no entry
+    point of the class ever evaluates -- their storage was packed without regard to them, Lowering.dead_groups)"""
     nh = len(headers) // 8
     for r0 in range(0, len(table), 2 * W):
+        if W > 1 and r0 // (2 * W) not in unwalked:
+            steps = []                                    # per wave: [(reads, writes) per step]
+            for k in range(W):
+                cur, mine = (set(), set()), []
+                for h in range(table[r0 + 2 * k], table[r0 + 2 * k + 1]):
+                    hdr = headers[8 * h:8 * h + 8]
+                    if (hdr[0] >> 8) == K_BARRIER:
+                        mine.append(cur)
+                        cur = (set(), set())
+                        continue
+                    rd, wr = record_accesses(words, hdr)
+                    cur[0].update(rd)
+                    cur[1].update(wr)
+                    if hdr[5] & F_BARRIER_AFTER:
+                        mine.append(cur)
+                        cur = (set(), set())
+                mine.append(cur)
+                steps.append(mine)
+            for st in range(max(len(m_) for m_ in steps)):
+                acc = [m_[st] if st < len(m_) else (set(), set()) for m_ in steps]
+                for k in range(W):
+                    wk = acc[k][1] - {dummy}
+                    if not wk:
+                        continue
+                    for j in range(W):
+                        if j != k and (wk & acc[j][0] or (j > k and wk & (acc[j][1] - {dummy}))):
+                            raise AssertionError("step %d of range %d: wave %d writes what wave %d touches (%s)"
+                                                 % (st, r0 // (2 * W), k, j, sorted(wk & (acc[j][0] | acc[j][1]))[:4]))
         bars = set()
         for k in range(W):
             h0, h1 = table[r0 + 2 * k], table[r0 + 2 * k + 1]

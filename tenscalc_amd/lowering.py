@@ -427,6 +427,7 @@ class Lowering:
                 if e["name"] in tl["time"] or e["name"].endswith("_getOutputs"):
                     alive |= set(e["parents"])
             dead = set(range(1, T.nGroups + 1)) - alive
+        self.dead_groups = set(dead)         # diagnostics / ldsm_schedule.validate: ranges nothing ever walks
 
         def life(i):
             g = int(grp[i])

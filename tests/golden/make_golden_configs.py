@@ -97,15 +97,20 @@ def sls_trace(nseeds=12):
     print("sls trace:", len(rows), "rows for", nseeds, "seeds")
 
 
-def main():
+def main(which=("sls_trace", "dcmotor", "l1l2", "quadcopter")):
+    """python tests/golden/make_golden_configs.py [sls_trace] [dcmotor] [l1l2] [quadcopter]   (default: all)"""
     from tenscalc_amd.problems.mpc_dcmotor import SOLVE_ARGS as A1, dcmotor_data, mpc_dcmotor
     from tenscalc_amd.problems.l1l2 import SOLVE_ARGS as A2, l1l2, l1l2_data
     from tenscalc_amd.problems.mpc_quadcopter import SOLVE_ARGS as A3, mpc_quadcopter, quadcopter_data
-    sls_trace()
-    _solve_all(mpc_dcmotor(folder="/tmp/golden_gen"), "dcmotor", dcmotor_data, range(100, 132), A1)
-    _solve_all(l1l2(folder="/tmp/golden_gen"), "l1l2", l1l2_data, range(10, 16), A2)
-    _solve_all(mpc_quadcopter(folder="/tmp/golden_gen"), "quadcopter", quadcopter_data, range(20, 26), A3, extra_maxiter=(1,))
+    if "sls_trace" in which:
+        sls_trace()
+    if "dcmotor" in which:
+        _solve_all(mpc_dcmotor(folder="/tmp/golden_gen"), "dcmotor", dcmotor_data, range(100, 132), A1)
+    if "l1l2" in which:
+        _solve_all(l1l2(folder="/tmp/golden_gen"), "l1l2", l1l2_data, range(10, 16), A2)
+    if "quadcopter" in which:
+        _solve_all(mpc_quadcopter(folder="/tmp/golden_gen"), "quadcopter", quadcopter_data, range(20, 26), A3, extra_maxiter=(1,))
 
 
 if __name__ == "__main__":
-    main()
+    main(tuple(sys.argv[1:]) or ("sls_trace", "dcmotor", "l1l2", "quadcopter"))

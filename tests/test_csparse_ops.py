@@ -200,6 +200,105 @@ def test_min_degree_order_is_a_permutation_and_limits_fill():
     assert p[-1] == 0 or p[-2] == 0
 
 
+def _tridiag(n):
+    rows = list(range(n)) + list(range(n - 1)) + list(range(1, n))
+    cols = list(range(n)) + list(range(1, n)) + list(range(n - 1))
+    return rows, cols
+
+
+def test_multiple_elimination_order_reduces_a_chain_odd_even():
+    """a tridiagonal matrix: front-to-back elimination has a dependency chain of n, rounds of independent
+    nodes within one of the minimum degree reduce it odd-even (cyclic reduction) at twice the fill"""
+    from tenscalc_amd.csparse import multiple_elimination_order, symbolic_ldl_cost
+    n = 257
+    rows, cols = _tridiag(n)
+    p0 = min_degree_order(n, rows, cols)
+    p1 = multiple_elimination_order(n, rows, cols, slack=1)      # the two ends have degree 1, the interior 2
+    assert sorted(p1.tolist()) == list(range(n))
+    c0, c1 = symbolic_ldl_cost(n, rows, cols, p0, term_weight=0.0), symbolic_ldl_cost(n, rows, cols, p1, term_weight=0.0)
+    assert c0["nnzL"] == n - 1 and c0["depth"] >= 2 * (n - 2)        # the chain: factor + forward + backward
+    assert c1["nnzL"] <= 2 * n and c1["depth"] <= 6 * np.ceil(np.log2(n))
+
+
+def test_multiple_elimination_order_respects_the_gates():
+    """equality duals (stage 1) only after one eliminated primal neighbour; a primal node only after ALL its
+    inequality duals (stage 2)"""
+    from tenscalc_amd.csparse import multiple_elimination_order
+    rs = np.random.RandomState(3)
+    nU, nG, nF = 20, 8, 12
+    n = nU + nG + nF
+    rows, cols = list(range(n)), list(range(n))
+    for i in range(nU - 1):
+        rows += [i, i + 1]; cols += [i + 1, i]
+    for g in range(nG):
+        for u in rs.choice(nU, 3, replace=False):
+            rows += [nU + g, u]; cols += [u, nU + g]
+    for f in range(nF):
+        u = rs.randint(nU)
+        rows += [nU + nG + f, u]; cols += [u, nU + nG + f]
+    stages = [0] * nU + [1] * nG + [2] * nF
+    adj = [set() for _ in range(n)]
+    for r, c in zip(rows, cols):
+        if r != c:
+            adj[r].add(c)
+    for slack in (0, 2, 8):
+        p = multiple_elimination_order(n, rows, cols, stages, slack)
+        assert sorted(p.tolist()) == list(range(n))
+        pos = np.empty(n, dtype=int); pos[p] = np.arange(n)
+        for g in range(nU, nU + nG):
+            assert min(pos[u] for u in adj[g] if u < nU) < pos[g]
+        for u in range(nU):
+            assert all(pos[f] < pos[u] for f in adj[u] if f >= nU + nG)
+
+
+@pytest.mark.parametrize("order", [("mmd", 0), ("mmd", 3), ("depth", 64)])
+def test_ldl_with_parallel_orders_solves_like_numpy(tape_oracle, order):
+    """the factorisation and both triangular solves under the depth-aware orders: L*diag(D)*L' == A(p,p),
+    ldl(A)\\b == A\\b (testFactorizations.m:74-90, testLDL.m:84-92) on a banded matrix"""
+    rs = np.random.RandomState(11)
+    n = 40
+    Mv = np.zeros((n, n))
+    for k in (1, 2):
+        v = rs.randn(n - k)
+        Mv += np.diag(v, k) + np.diag(v, -k)
+    Mv += np.diag(np.abs(Mv).sum(1) + 1.0)
+    nz = np.argwhere(Mv != 0)
+    vals = tc.Tvariable("vals", (len(nz),))
+    E = np.zeros((n, n, len(nz)))
+    for k, (i, j) in enumerate(nz):
+        E[i, j, k] = 1.0
+    Asym = tc.tprod(tc.Tconstant(E), (1, 2, -1), vals, (-1,))
+    b = tc.Tvariable("b", (n,))
+    F = tc.ldl(Asym)
+    outs = {"x": tc.full(tc.mldivide(F, b)), "d": tc.ldl_d(F), "L": tc.full(tc.ldl_l(F))}
+    bv = rs.randn(n)
+    import tenscalc_amd.csparse as cs
+    old = cs.LDL_ORDER
+    cs.LDL_ORDER = order
+    try:
+        got, tape, code = run(tape_oracle, [vals, b], [Mv[nz[:, 0], nz[:, 1]], bv], outs)
+    finally:
+        cs.LDL_ORDER = old
+    p = code.ldl_perm[F.idx]
+    L, d = got["L"], got["d"]
+    np.testing.assert_allclose(L @ np.diag(d) @ L.T, Mv[np.ix_(p, p)], rtol=0, atol=1e3 * EPS * np.abs(Mv).max() * n)
+    np.testing.assert_allclose(got["x"], np.linalg.solve(Mv, bv), rtol=1e-11, atol=1e-12)
+    assert cs.symbolic_ldl_cost(n, nz[:, 0], nz[:, 1], p)["depth"] < cs.symbolic_ldl_cost(
+        n, nz[:, 0], nz[:, 1], min_degree_order(n, nz[:, 0], nz[:, 1]))["depth"]
+
+
+def test_depth_aware_order_keeps_tolerance_zero_with_equality_duals():
+    """with stage-1 nodes in the matrix the search stays with the greedy order or tolerance 0 (numerical finding of
+    DESIGN.md 7); without them it may trade fill for depth"""
+    from tenscalc_amd.csparse import depth_aware_order, multiple_elimination_order
+    n = 64
+    rows, cols = _tridiag(n)
+    rows += [n, 0, n, 5]; cols += [0, n, 5, n]; rows.append(n); cols.append(n)
+    stages = [0] * n + [1]
+    p = depth_aware_order(n + 1, rows, cols, stages, width=64)
+    assert (p == multiple_elimination_order(n + 1, rows, cols, stages, 0)).all() or (p == min_degree_order(n + 1, rows, cols, stages)).all()
+
+
 def test_dedup_makes_symmetric_products_share_instructions(native_built):
     """A'*A: entry (i,j) and (j,i) must be the same instruction (needed by the symmetry test of
     sparsity_ldl.m:65-75; csparse.m:1168-1227 normalize)."""

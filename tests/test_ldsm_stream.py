@@ -264,6 +264,34 @@ def test_ldsm_validator_rejects_bad_addresses(sls_spec):
         lsch.validate(w, cs["headers"], cs["table"], cs["W"], cs["nLds"], cs["nLds"] + cs["nGlob"])
 
 
+def test_ldsm_validator_rejects_a_cross_wave_hazard_inside_a_step():
+    """the waves of a step run side by side on the device: a record of one wave must not write what a record of
+    another wave reads or writes before the next barrier.  The schedules built for W=4 pass; redirecting one
+    destination onto an operand of another wave's record of the same step is caught (a sequential model that runs
+    the waves one after the other would compute SOME value and say nothing)."""
+    from tenscalc_amd.problems.mpc_dcmotor import mpc_dcmotor
+    spec = mpc_dcmotor(folder="/tmp/ldsm_hazard_gen")
+    cs = lsch.class_stream(spec.tape, spec.classname, spec.defines, W=4)
+    W, hdrs, table = cs["W"], np.asarray(cs["headers"]).reshape(-1, 8), cs["table"]
+    nA = cs["nLds"] + cs["nGlob"]
+    dead = {cs["rid"][g_] for g_ in cs["lowering"].dead_groups if g_ in cs["rid"]}
+    lsch.validate(cs["words"], cs["headers"], table, W, cs["nLds"], nA, dummy=cs["dummy"], unwalked=dead)   # as built: clean
+    # find a range in which wave 0 and wave 1 both have a SHORT record in their first step
+    for r0 in range(0, len(table), 2 * W):
+        if r0 // (2 * W) in dead:
+            continue
+        h0, h1 = table[r0], table[r0 + 2]
+        if table[r0 + 1] > h0 and table[r0 + 3] > h1 and hdrs[h0, 0] >> 8 == lsch.K_SHORT and hdrs[h1, 0] >> 8 == lsch.K_SHORT:
+            rd1, _ = lsch.record_accesses(cs["words"], hdrs[h1])
+            victim = next(a for a in sorted(rd1) if a != cs["dummy"] and a < cs["nLds"])
+            w = list(cs["words"])
+            w[int(hdrs[h0, 4])] = victim                   # wave 0's first destination := an operand of wave 1
+            with pytest.raises(AssertionError, match="writes what wave"):
+                lsch.validate(w, cs["headers"], table, W, cs["nLds"], nA, dummy=cs["dummy"], unwalked=dead)
+            return
+    pytest.skip("no range with two parallel short records")
+
+
 @pytest.mark.parametrize("op", [I.I_min, I.I_min0, I.I_max, I.I_max0, I.I_clp])
 def test_two_level_fold_equals_the_reference_chain(op):
     """ldsm_schedule._SPLIT: a long minimum / maximum folded chunk by chunk (chunks from +-inf, the reference's leading
