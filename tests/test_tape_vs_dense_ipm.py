@@ -106,3 +106,31 @@ def test_l1l2_small_vs_scipy(native_built, tape_oracle, tmp_path):
     print("\nl1l2 N=24: tape optimum J=%.9g, scipy SLSQP J=%.9g (status %d)" % (y[0], ref.fun, ref.status))
     assert abs(y[0] - ref.fun) <= 2e-3 * (1 + abs(ref.fun))               # desiredDualityGap 1e-3 (scaled cost)
     assert y[0] >= ref.fun - 1e-6 * (1 + abs(ref.fun))                    # an interior point: never below the optimum
+
+
+def test_quadcopter_tape_vs_dense_nlp_ipm(native_built, tape_oracle, tmp_path):
+    """mpc_quadcopter T=100 (nonlinear equality and inequality constraints, non-convex: 700 primal variables, 1406x1406
+    KKT): the scalar tape against a dense interior-point method whose objective and constraints are written by hand
+    in torch (tests/dense_ipm.py: quadcopter_model) and differentiated by torch.autograd -- nothing of
+    tcalculus.py / csparse.py is involved on that side.  Same status and iteration count; the primal iterate after
+    1 and 3 Newton iterations and the returned optimum agree to 1e-7 relative (measured: 1e-11 .. 3e-10; the KKT
+    matrix has condition 2e8 and the two sides factor it differently)."""
+    from dense_ipm import quadcopter_model, solve_nlp_dense
+    from tenscalc_amd.problems.mpc_quadcopter import SOLVE_ARGS, mpc_quadcopter, quadcopter_data
+    spec = mpc_quadcopter(folder=str(tmp_path))
+    d = quadcopter_data(23)
+    model, u0 = quadcopter_model(d)
+    assert len(u0) == spec.defines["nU"]
+    import torch
+    z0 = torch.as_tensor(u0)
+    assert (len(model["G"](z0)), len(model["F"](z0))) == (spec.defines["nG"], spec.defines["nF"])
+    sl = _outputs_slices(spec)
+    runs = _oracle_runs(spec, tape_oracle, d, SOLVE_ARGS, [1, 3, SOLVE_ARGS["maxIter"]])
+    for mi, (st, it, y) in runs.items():
+        dst, dit, u, _, _ = solve_nlp_dense(model, u0, SOLVE_ARGS["mu0"], mi)
+        assert (st & 15, it) == (dst, dit), (mi, st, it, dst, dit)
+        got = np.r_[y[sl["p"]], y[sl["u"]], y[sl["positive2"]]]
+        assert np.abs(got - u).max() <= 1e-7 * (1 + np.abs(u).max()), (mi, np.abs(got - u).max())
+        J = float(model["f"](torch.as_tensor(u)))
+        assert abs(y[sl["J"]][0] - J) <= 1e-8 * (1 + abs(J))
+    assert runs[SOLVE_ARGS["maxIter"]][0] == 0
