@@ -139,6 +139,8 @@ class Printer:
                 if isinstance(k, str):          # rolled sweep: row block index is a loop variable
                     return f"TC_SD({d['off'] + vec[2] * d['K']} + {k})"
                 return f"TC_SD({d['off'] + vec[2] * d['K'] + k})"
+            if d.get("agpr"):
+                return f"TC_AX({vec[1]}, {vec[2] * d['K'] + k})"
             return f"c.dX{vec[1]}[{vec[2] * d['K'] + k}]"
         return f"c.dF{vec[1]}[{k}]"
 
@@ -987,8 +989,13 @@ def _mask(groups):
 def emit_class(spec, fp_contract="fast", block=64, stats=False, roll=True, min_waves=0, lanes=1,
                recip=False, fast_div=False, inline_max=0, reg_budget=150, scratch="auto", body="code",
                waves=1, fuse=False, static_clean=False, forward=False, rcache=0, lds_state=0, share=False,
-               branch_free_tails=True, exact=False, stg_blocks=0, ilp=False, fw_window=0, sched_every=0):
+               branch_free_tails=True, exact=False, stg_blocks=0, ilp=False, fw_window=0, sched_every=0, agpr=False):
     """Return the HIP source text of the solver class.
+
+    agpr=True (lanes>1, one wavefront per SIMD): the register-resident lane-distributed inputs live in the accumulator
+    half of the register file for the whole kernel (v_accvgpr_write once, v_accvgpr_read at each use) instead of being
+    ordinary values the allocator shuffles between the two halves: the 256 architectural VGPRs stay free for the
+    code between the sweeps.
 
     exact=True (lanes>1, fp_contract='off', no recip/fast_div): the wave-cooperative lowering with the
     reference's arithmetic kept bit for bit (Printer.exact_dsweeps / lane_reduction): same outputs, status and
@@ -1104,9 +1111,17 @@ def emit_class(spec, fp_contract="fast", block=64, stats=False, roll=True, min_w
         d["resident"] = d["rest"] * d["K"] <= budget
         if d["resident"]:
             budget -= d["rest"] * d["K"]
+    aroom = 124 if (agpr and lanes > 1) else 0       # doubles: 248 of the 256 accumulator registers
+    for d in sorted([x for x in L.inputs if x["dist"] and x["resident"]], key=lambda x: -x["rest"] * x["K"]):
+        d["agpr"] = d["rest"] * d["K"] <= aroom
+        if d["agpr"]:
+            aroom -= d["rest"] * d["K"]
     for d in L.inputs:
         if d["dist"] and d["resident"]:
-            dmembers += f"  double dX{d['arr']}[{d['rest'] * d['K']}];\n"
+            if d["agpr"]:
+                dmembers += f"  unsigned aX{d['arr']}[{2 * d['rest'] * d['K']}];\n"
+            else:
+                dmembers += f"  double dX{d['arr']}[{d['rest'] * d['K']}];\n"
     if any(d["dist"] and not d["resident"] for d in L.inputs):
         w.append("#define TC_SD32 1\n")
     for f in L.dfamilies.values():
@@ -1391,8 +1406,13 @@ def emit_class(spec, fp_contract="fast", block=64, stats=False, roll=True, min_w
     for d in L.inputs:
         if d["dist"] and d["resident"]:
             cnt = d["rest"] * d["K"]
-            prologue += (f"  _Pragma(\"unroll\") for (int j = 0; j < {cnt}; j++) "
-                         f"c.dX{d['arr']}[j] = Sd[((long)({d['off']} + j) * B + tid) * TC_P + c.lane];\n")
+            if d.get("agpr"):
+                prologue += (f"  _Pragma(\"unroll\") for (int j = 0; j < {cnt}; j++) "
+                             f"tc_awrite(Sd[((long)({d['off']} + j) * B + tid) * TC_P + c.lane], "
+                             f"c.aX{d['arr']}[2 * j], c.aX{d['arr']}[2 * j + 1]);\n")
+            else:
+                prologue += (f"  _Pragma(\"unroll\") for (int j = 0; j < {cnt}; j++) "
+                             f"c.dX{d['arr']}[j] = Sd[((long)({d['off']} + j) * B + tid) * TC_P + c.lane];\n")
     if prologue_push and P.fuse and lanes > 1 and pushed_first:
         # the parameter-only distributed groups, evaluated once per solve right here: their sums over inputs
         # that are not resident in registers share ONE sweep (A'A and A'b: one pass over A instead of two),
@@ -1763,7 +1783,8 @@ def build_class(spec, fp_contract="fast", arch="gfx950", opt="-O3", block=64, fo
                 outdir=None, stats=False, tag=None, extra_flags=(), roll=True, min_waves=0, lanes=1,
                 recip=False, fast_div=False, inline_max=0, reg_budget=150, scratch="auto", body="code",
                 waves=1, fuse=False, static_clean=False, forward=False, rcache=0, lds_state=0, share=False,
-                branch_free_tails=True, exact=False, stg_blocks=0, lds_slots=20000, ilp=False, fw_window=0, sched_every=0):
+                branch_free_tails=True, exact=False, stg_blocks=0, lds_slots=20000, ilp=False, fw_window=0, sched_every=0,
+                agpr=False):
     """Emit <cls>.hip (+ <cls>.h, <cls>.tape) and compile lib<cls>.so with hipcc for gfx950.
     Mirrors the createGateway/compile step of cmex2optimizeCS.m:403-417."""
     from .tapeio import save_tape, tape_records, _rec
@@ -1780,7 +1801,8 @@ def build_class(spec, fp_contract="fast", arch="gfx950", opt="-O3", block=64, fo
     kq.update(repr((cls, sorted(spec.defines.items()), [(n, tuple(sz)) for n, sz in spec.outputs], fp_contract, arch, opt, block,
                     stats, tag, tuple(extra_flags), roll, min_waves, lanes, recip, fast_div, inline_max, reg_budget, scratch,
                     body, waves, fuse, static_clean, forward, rcache, lds_state, share, branch_free_tails, exact, stg_blocks,
-                    lds_slots, ilp, fw_window, sched_every, os.environ.get("TC_LDS_PAD_SLOTS", ""), os.environ.get("TC_SWEEP_UNROLL", ""))).encode())
+                    lds_slots, ilp, fw_window, sched_every, agpr, os.environ.get("TC_LDS_PAD_SLOTS", ""),
+                    os.environ.get("TC_SWEEP_UNROLL", ""))).encode())
     for f_ in sorted(os.listdir(HERE)):
         if f_.endswith(".py"):
             kq.update(open(os.path.join(HERE, f_), "rb").read())
@@ -1803,7 +1825,7 @@ def build_class(spec, fp_contract="fast", arch="gfx950", opt="-O3", block=64, fo
                         reg_budget=reg_budget, scratch=scratch, body=body, waves=waves, fuse=fuse,
                         static_clean=static_clean, forward=forward, rcache=rcache, lds_state=lds_state,
                         share=share, branch_free_tails=branch_free_tails, exact=exact, stg_blocks=stg_blocks, ilp=ilp,
-                        fw_window=fw_window, sched_every=sched_every)
+                        fw_window=fw_window, sched_every=sched_every, agpr=agpr)
     hip = os.path.join(outdir, f"{cls}{suffix}.hip")
     so = os.path.join(outdir, f"lib{cls}{suffix}.so")
     flags = [opt, f"--offload-arch={arch}", "-fPIC", "-shared", "-std=c++17",
