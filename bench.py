@@ -64,6 +64,12 @@ def main():
                     help="sls (default): BASELINE.json's metric, configs[1].  The others are BASELINE configs[2..4] in the "
                          "same JSON vocabulary: l1l2 16384 instances, dcmotor 32768 (the whole 8-GPU sweep on one GPU), "
                          "quadcopter 512 (configs[4]'s per-GPU share of 4096) per GPU; --batch overrides")
+    ap.add_argument("--pipeline", type=int, default=1,
+                    help="--config runs only: number of batches in flight (that many solver handles, each on a stream of "
+                         "its own, steps issued round-robin).  1 (default) = one batched solve after the other.  With >1 the "
+                         "slowest instance of a batch -- mpc_quadcopter: 371 Newton iterations against a median of 28 -- no "
+                         "longer idles the other 255 CUs: they start on the next batch.  Every step is still one complete "
+                         "batched solve; reported under config.pipeline")
     ap.add_argument("--gather-every-step", action="store_true",
                     help="N>1: all-gather the results after EVERY step (overlapped with the next solve) instead of once "
                          "after the K steps (SURVEY.md 8e: one gather at the end)")
@@ -387,22 +393,28 @@ def bench_config(args):
     nd = min(B, 256)                                           # 256 distinct seeded instances, tiled over the batch
     ds = [getattr(mod, datafn)(rank * 256 + k) for k in range(nd)]
     stacked = {n: np.stack([np.asarray(ds[k % nd][n], dtype=float).reshape(-1, order="F") for k in range(B)]) for n in names}
-    obj = HipSolver(so, B=B, device=local)
-    for n in names:
-        obj.set(n, stacked[n])
-    stream = torch.cuda.current_stream().cuda_stream
+    P = max(1, int(args.pipeline))
+    objs = [HipSolver(so, B=B, device=local) for _ in range(P)]
+    for o_ in objs:
+        for n in names:
+            o_.set(n, stacked[n])
+    obj = objs[0]
+    streams = [torch.cuda.current_stream()] + [torch.cuda.Stream(device=dev) for _ in range(P - 1)]
     ae = SOLVE.get("addEye2Hessian", (1e-9, 1e-9))
-    for _ in range(args.warmup):
-        obj.solve_async(SOLVE["mu0"], SOLVE["maxIter"], ae, stream=stream)
+    for k in range(args.warmup * P):
+        objs[k % P].solve_async(SOLVE["mu0"], SOLVE["maxIter"], ae, stream=streams[k % P].cuda_stream)
     evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
     if world > 1:
         dist.barrier(device_ids=[local])
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for k in range(args.steps):
-        evs[k][0].record()
-        obj.solve_async(SOLVE["mu0"], SOLVE["maxIter"], ae, stream=stream)
-        evs[k][1].record()
+        s_ = streams[k % P]
+        evs[k][0].record(s_)
+        objs[k % P].solve_async(SOLVE["mu0"], SOLVE["maxIter"], ae, stream=s_.cuda_stream)
+        evs[k][1].record(s_)
+    for s_ in streams[1:]:
+        torch.cuda.current_stream().wait_stream(s_)
     optr, sptr, iptr = obj.device_views()
     nout = sum(o["numel"] for o in obj.outputs)
     ST = torch.as_tensor(_DevArray(sptr, (B,), "<i4"), device=dev)
@@ -437,6 +449,7 @@ def bench_config(args):
                "dtype": "f64", "data": "synthetic",
                "config": {"workload": label % B, "batch_per_gpu": B, "mu0": SOLVE["mu0"], "maxIter": SOLVE["maxIter"],
                           "variant": variant, "parity_class": g.PARITY_CLASS.get(variant, "solver-tolerance"),
+                          "pipeline": P,
                           "solved_fraction": float(ok.item()) / (B * world), "iter_median": float(np.median(it)),
                           "iter_max": int(it.max()),
                           "sharding": "independent instances per rank; one RCCL all_gather of the results after the K steps"},
@@ -454,7 +467,8 @@ def bench_config(args):
     if world > 1:
         dist.barrier(device_ids=[local])
         dist.destroy_process_group()
-    obj.close()
+    for o_ in objs:
+        o_.close()
 
 
 def cpu_baseline_config(spec, which, stacked, names, n, SOLVE, st, it):
