@@ -110,6 +110,10 @@ int64_t tc_probe_numel(const char *getName);
  * out is [tc_stats_rows()][B].  All zero for ordinary builds. */
 int64_t tc_stats_rows(void);
 int tc_get_stats(tc_solver_t *h, double *out);
+/* the reference's profilingView(filename) (lib/@csparse/writeCprofiling.c:8-83, classes generated with profiling=true):
+ * per dependency group executions and time of the last batched solve, averaged over its instances, written to
+ * `filename` in the reference's table layout.  TC_EINVAL for classes built without stats=True. */
+int tc_profiling_view(tc_solver_t *h, const char *filename);
 
 #ifdef __cplusplus
 }

@@ -75,6 +75,7 @@ def _bind(path):
     L.tc_probe.argtypes = [c.c_void_p, c.c_char_p, c.c_double, _dp, _dp, c.c_int64]
     L.tc_stats_rows.restype = c.c_int64
     L.tc_get_stats.argtypes = [c.c_void_p, _dp]
+    L.tc_profiling_view.argtypes = [c.c_void_p, c.c_char_p]
     L.tc_probe_numel.restype = c.c_int64
     L.tc_probe_numel.argtypes = [c.c_char_p]
     return L
@@ -212,6 +213,11 @@ class HipSolver:
         out = np.zeros((rows, self.B))
         self._check(self._L.tc_get_stats(self._h, out.ctypes.data_as(_dp)))
         return out
+
+    def profilingView(self, filename):
+        """the reference class's profilingView(obj, filename) (writeCprofiling.c:8-83): per dependency group executions and
+        time of the last solve, averaged over the batch; classes built with stats=True only"""
+        self._check(self._L.tc_profiling_view(self._h, os.fsencode(filename)))
 
     def probe(self, get_name, mu0=1.0, addEye2Hessian=(1e-9, 1e-9)):
         """evaluate a tape get entry point after the solver's initialisation sequence -> [B, numel]"""

@@ -108,3 +108,37 @@ def test_quadcopter_full_batch_properties():
         z = torch.as_tensor(np.r_[out["p"][k], out["u"][k], out["positive2"][k]])
         assert abs(out["J"][k, 0] - float(model["f"](z))) <= 1e-9 * (1 + abs(out["J"][k, 0]))
         assert float(model["G"](z).abs().max()) <= 1e-4 and float(model["F"](z).min()) > 0
+
+
+def test_profiling_view_through_the_boundary(tmp_path):
+    """the reference's profilingView(filename) (writeCprofiling.c:8-83) on a class built with stats=True (the reference's
+    profiling=true): one row per dependency group with executions and time, totals, phases; ordinary classes refuse;
+    the counters do not change any result"""
+    import __graft_entry__ as g
+    from tenscalc_amd.problems.sls import SOLVE_ARGS, sls_batch
+    from tenscalc_amd.runtime import HipSolver
+    spec = g.sls_spec("strict")
+    B = 256
+    A, b, x0 = sls_batch(B, seed0=500)
+    res = {}
+    for tag, kw in (("plain", g.VARIANT_KW["strict"]), ("stats", dict(g.VARIANT_KW["strict"], stats=True, tag="strict_stats"))):
+        obj = HipSolver(spec.build(**kw), B=B)
+        obj.set("A", np.ascontiguousarray(np.transpose(A, (0, 2, 1)))); obj.set("b", b); obj.set("x", x0)
+        st, it, _ = obj.solve(**SOLVE_ARGS)
+        res[tag] = (st, it, [o.copy() for o in obj.getOutputs()])
+        path = str(tmp_path / (tag + ".profile"))
+        if tag == "plain":
+            with pytest.raises(RuntimeError, match="without profiling"):
+                obj.profilingView(path)
+        else:
+            obj.profilingView(path)
+            txt = open(path).read().splitlines()
+            rows = [ln.split() for ln in txt[1:1 + spec.tape.nGroups]]
+            assert [int(r[0]) for r in rows] == list(range(spec.tape.nGroups))
+            execs = np.array([float(r[2]) for r in rows]); tus = np.array([float(r[3]) for r in rows])
+            assert execs.max() >= it.mean() - 2 and (tus >= 0).all() and tus.sum() > 0
+            assert txt[1 + spec.tape.nGroups].startswith("Total") and any(ln.startswith("Phase of the Newton loop") for ln in txt)
+        obj.close()
+    assert np.array_equal(res["plain"][0], res["stats"][0]) and np.array_equal(res["plain"][1], res["stats"][1])
+    for a, b_ in zip(res["plain"][2], res["stats"][2]):
+        assert np.array_equal(a, b_)
