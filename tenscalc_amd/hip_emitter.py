@@ -84,7 +84,6 @@ class Printer:
         # other lanes of the instance write other slots)
         self.forward = False
         self.sched_every = 0        # a scheduling barrier after every sched_every single operands of a lane reduction
-        self.prefetch = 0           # lanes>1: at most this many constant-slot LDS operands of a group are read up front
         self.fw_window = 0          # forward a value only to the next fw_window units of its group (0: to all of them);
         #                             in a 647-instruction LDL every early factor entry would otherwise stay live in a
         #                             register to the end of the group -- 1 500 scratch accesses in mpc_dcmotor's
@@ -140,8 +139,6 @@ class Printer:
                 if isinstance(k, str):          # rolled sweep: row block index is a loop variable
                     return f"TC_SD({d['off'] + vec[2] * d['K']} + {k})"
                 return f"TC_SD({d['off'] + vec[2] * d['K'] + k})"
-            if d.get("agpr"):
-                return f"TC_AX({vec[1]}, {vec[2] * d['K'] + k})"
             return f"c.dX{vec[1]}[{vec[2] * d['K'] + k}]"
         return f"c.dF{vec[1]}[{k}]"
 
@@ -861,39 +858,7 @@ class Printer:
         if self._pending:      # later groups / entry points read through LDS
             out.append("  __builtin_amdgcn_wave_barrier();\n")
             self._pending = []
-        text = "".join(out)
-        if self.prefetch and L.P > 1:
-            text = self._prefetch_group_inputs(text, int(self.prefetch))
-        return text
-
-    def _prefetch_group_inputs(self, text, cap):
-        """Operands a group reads from LDS by constant slot and never writes itself are values of EARLIER groups: they
-        are all available when the group starts.  Left alone, the register-pressure minimising scheduler pairs every
-        such load with its first use and waits for each in turn -- a serial chain of LDS round trips through code
-        whose arithmetic is itself a dependent chain (triangular solves, pivots).  Here they are read into locals
-        back to back at the top of the group, behind a scheduling barrier (the same cure as for the staged terms of
-        the ordered sums).  Values are untouched: the same loads, earlier."""
-        import re
-        written = []
-        for m in re.finditer(r"MM\(((?:[^()]|\([^()]*\))*)\)\s*=(?!=)", text):
-            nums = [int(x) for x in re.findall(r"(?<![\w.])(\d+)(?![\w.])", m.group(1))]
-            if not nums:
-                return text                 # a destination that cannot be told: leave the group alone
-            wide = 63 if re.search(r"c_|j_|lane", m.group(1)) else 0
-            written.append((min(nums) - wide, max(nums) + wide))
-        order, seen = [], set()
-        for m in re.finditer(r"MM\((\d+)\)(?!\s*=(?!=))", text):
-            k = int(m.group(1))
-            if k not in seen and not any(lo <= k <= hi for lo, hi in written):
-                seen.add(k)
-                order.append(k)
-        order = order[:cap]
-        if len(order) < 4:
-            return text
-        keep = set(order)
-        text = re.sub(r"MM\((\d+)\)(?!\s*=(?!=))", lambda m: f"pf{m.group(1)}_" if int(m.group(1)) in keep else m.group(0), text)
-        head = "".join(f"  const double pf{k}_ = MM({k});\n" for k in order) + "  __builtin_amdgcn_sched_barrier(0);\n"
-        return head + text
+        return "".join(out)
 
     # ---- register cache of hot replicated values (lanes>1) ----------------------------------------
     def setup_rcache(self, budget):
@@ -1022,14 +987,8 @@ def _mask(groups):
 def emit_class(spec, fp_contract="fast", block=64, stats=False, roll=True, min_waves=0, lanes=1,
                recip=False, fast_div=False, inline_max=0, reg_budget=150, scratch="auto", body="code",
                waves=1, fuse=False, static_clean=False, forward=False, rcache=0, lds_state=0, share=False,
-               branch_free_tails=True, exact=False, stg_blocks=0, ilp=False, fw_window=0, sched_every=0, agpr=False,
-               prefetch=0):
+               branch_free_tails=True, exact=False, stg_blocks=0, ilp=False, fw_window=0, sched_every=0):
     """Return the HIP source text of the solver class.
-
-    agpr=True (lanes>1, one wavefront per SIMD): the register-resident lane-distributed inputs live in the accumulator
-    half of the register file for the whole kernel (v_accvgpr_write once, v_accvgpr_read at each use) instead of being
-    ordinary values the allocator shuffles between the two halves: the 256 architectural VGPRs stay free for the
-    code between the sweeps.
 
     exact=True (lanes>1, fp_contract='off', no recip/fast_div): the wave-cooperative lowering with the
     reference's arithmetic kept bit for bit (Printer.exact_dsweeps / lane_reduction): same outputs, status and
@@ -1079,7 +1038,6 @@ def emit_class(spec, fp_contract="fast", block=64, stats=False, roll=True, min_w
     P.exact = bool(exact) and lanes > 1
     P.ilp = bool(ilp)
     P.fw_window = int(fw_window)
-    P.prefetch = int(prefetch)
     P.sched_every = int(sched_every)
     if P.exact and (recip or fast_div or fuse or fp_contract != "off"):
         raise ValueError("exact=True needs fp_contract='off' and no recip/fast_div/fuse")
@@ -1146,17 +1104,9 @@ def emit_class(spec, fp_contract="fast", block=64, stats=False, roll=True, min_w
         d["resident"] = d["rest"] * d["K"] <= budget
         if d["resident"]:
             budget -= d["rest"] * d["K"]
-    aroom = 124 if (agpr and lanes > 1) else 0       # doubles: 248 of the 256 accumulator registers
-    for d in sorted([x for x in L.inputs if x["dist"] and x["resident"]], key=lambda x: -x["rest"] * x["K"]):
-        d["agpr"] = d["rest"] * d["K"] <= aroom
-        if d["agpr"]:
-            aroom -= d["rest"] * d["K"]
     for d in L.inputs:
         if d["dist"] and d["resident"]:
-            if d["agpr"]:
-                dmembers += f"  unsigned aX{d['arr']}[{2 * d['rest'] * d['K']}];\n"
-            else:
-                dmembers += f"  double dX{d['arr']}[{d['rest'] * d['K']}];\n"
+            dmembers += f"  double dX{d['arr']}[{d['rest'] * d['K']}];\n"
     if any(d["dist"] and not d["resident"] for d in L.inputs):
         w.append("#define TC_SD32 1\n")
     for f in L.dfamilies.values():
@@ -1441,13 +1391,8 @@ def emit_class(spec, fp_contract="fast", block=64, stats=False, roll=True, min_w
     for d in L.inputs:
         if d["dist"] and d["resident"]:
             cnt = d["rest"] * d["K"]
-            if d.get("agpr"):
-                prologue += (f"  _Pragma(\"unroll\") for (int j = 0; j < {cnt}; j++) "
-                             f"tc_awrite(Sd[((long)({d['off']} + j) * B + tid) * TC_P + c.lane], "
-                             f"c.aX{d['arr']}[2 * j], c.aX{d['arr']}[2 * j + 1]);\n")
-            else:
-                prologue += (f"  _Pragma(\"unroll\") for (int j = 0; j < {cnt}; j++) "
-                             f"c.dX{d['arr']}[j] = Sd[((long)({d['off']} + j) * B + tid) * TC_P + c.lane];\n")
+            prologue += (f"  _Pragma(\"unroll\") for (int j = 0; j < {cnt}; j++) "
+                         f"c.dX{d['arr']}[j] = Sd[((long)({d['off']} + j) * B + tid) * TC_P + c.lane];\n")
     if prologue_push and P.fuse and lanes > 1 and pushed_first:
         # the parameter-only distributed groups, evaluated once per solve right here: their sums over inputs
         # that are not resident in registers share ONE sweep (A'A and A'b: one pass over A instead of two),
@@ -1818,8 +1763,7 @@ def build_class(spec, fp_contract="fast", arch="gfx950", opt="-O3", block=64, fo
                 outdir=None, stats=False, tag=None, extra_flags=(), roll=True, min_waves=0, lanes=1,
                 recip=False, fast_div=False, inline_max=0, reg_budget=150, scratch="auto", body="code",
                 waves=1, fuse=False, static_clean=False, forward=False, rcache=0, lds_state=0, share=False,
-                branch_free_tails=True, exact=False, stg_blocks=0, lds_slots=20000, ilp=False, fw_window=0, sched_every=0,
-                agpr=False, prefetch=0):
+                branch_free_tails=True, exact=False, stg_blocks=0, lds_slots=20000, ilp=False, fw_window=0, sched_every=0):
     """Emit <cls>.hip (+ <cls>.h, <cls>.tape) and compile lib<cls>.so with hipcc for gfx950.
     Mirrors the createGateway/compile step of cmex2optimizeCS.m:403-417."""
     from .tapeio import save_tape, tape_records, _rec
@@ -1836,7 +1780,7 @@ def build_class(spec, fp_contract="fast", arch="gfx950", opt="-O3", block=64, fo
     kq.update(repr((cls, sorted(spec.defines.items()), [(n, tuple(sz)) for n, sz in spec.outputs], fp_contract, arch, opt, block,
                     stats, tag, tuple(extra_flags), roll, min_waves, lanes, recip, fast_div, inline_max, reg_budget, scratch,
                     body, waves, fuse, static_clean, forward, rcache, lds_state, share, branch_free_tails, exact, stg_blocks,
-                    lds_slots, ilp, fw_window, sched_every, agpr, prefetch, os.environ.get("TC_LDS_PAD_SLOTS", ""),
+                    lds_slots, ilp, fw_window, sched_every, os.environ.get("TC_LDS_PAD_SLOTS", ""),
                     os.environ.get("TC_SWEEP_UNROLL", ""))).encode())
     for f_ in sorted(os.listdir(HERE)):
         if f_.endswith(".py"):
@@ -1860,7 +1804,7 @@ def build_class(spec, fp_contract="fast", arch="gfx950", opt="-O3", block=64, fo
                         reg_budget=reg_budget, scratch=scratch, body=body, waves=waves, fuse=fuse,
                         static_clean=static_clean, forward=forward, rcache=rcache, lds_state=lds_state,
                         share=share, branch_free_tails=branch_free_tails, exact=exact, stg_blocks=stg_blocks, ilp=ilp,
-                        fw_window=fw_window, sched_every=sched_every, agpr=agpr, prefetch=prefetch)
+                        fw_window=fw_window, sched_every=sched_every)
     hip = os.path.join(outdir, f"{cls}{suffix}.hip")
     so = os.path.join(outdir, f"lib{cls}{suffix}.so")
     flags = [opt, f"--offload-arch={arch}", "-fPIC", "-shared", "-std=c++17",
