@@ -1076,7 +1076,9 @@ def emit_class(spec, fp_contract="fast", block=64, stats=False, roll=True, min_w
         consts = isch.constant_rows(T, L)[0]
     dummy = 1 if (forward and lanes > 1 and branch_free_tails) else 0
     nmp = max(1, L.nPriv) + dummy                                  # + TC_DUMMY
-    if P.exact:                                                    # staging area of the ordered sums
+    if P.exact and L.dreduce:                                      # staging area of the ordered sums (only tapes that sum
+                                                                   # over lane-distributed operands have any: mpc_dcmotor at 32
+                                                                   # lanes carried 1 056 unused slots = 8.4 KB per instance)
         # stg_blocks=0: as many row blocks per round as fit while 4 wavefronts per CU (one per SIMD: the
         # distributed inputs are register resident) still share the 160 KB of LDS
         P.stg_base = nmp
