@@ -1,0 +1,84 @@
+"""Tuning aid: one class library under several sets of extra hipcc flags -- built in parallel (CPU container), timed and
+compared bit for bit with the first set (GPU box).
+   python scripts/flag_sweep.py build|run <sls|dcmotor|l1l2|quad> <variant> <B>"""
+import os
+import sys
+
+sys.path.insert(0, os.getcwd())
+import numpy as np
+
+import __graft_entry__ as g
+
+ILP = ("-mllvm", "-amdgpu-sched-strategy=iterative-ilp")
+SETS = {
+    "base": (),
+    "iterilp": ILP,
+    "iterilp_novec": ILP + ("-mllvm", "-amdgpu-load-store-vectorizer=0"),
+    "itermaxocc": ("-mllvm", "-amdgpu-sched-strategy=iterative-maxocc"),
+}
+mode, which, variant, B = sys.argv[1], sys.argv[2], sys.argv[3], int(sys.argv[4])
+if which == "sls":
+    from tenscalc_amd.problems.sls import SOLVE_ARGS
+    mk = lambda: g.sls_spec(variant)      # noqa: E731
+elif which == "l1l2":
+    from tenscalc_amd.problems.l1l2 import SOLVE_ARGS, l1l2, l1l2_data as data
+    mk = lambda: l1l2(folder=g.GENERATED)      # noqa: E731
+elif which == "quad":
+    from tenscalc_amd.problems.mpc_quadcopter import SOLVE_ARGS, mpc_quadcopter, quadcopter_data as data
+    mk = lambda: mpc_quadcopter(folder=g.GENERATED)      # noqa: E731
+else:
+    from tenscalc_amd.problems.mpc_dcmotor import SOLVE_ARGS, dcmotor_data as data, mpc_dcmotor
+    mk = lambda: mpc_dcmotor(folder=g.GENERATED)      # noqa: E731
+
+
+def build(name):
+    kw = dict(g.VARIANT_KW[variant])
+    kw["tag"] = variant + "_f" + name
+    kw["extra_flags"] = SETS[name]
+    try:
+        return name, mk().build(**kw)
+    except Exception as e:      # a flag this compiler does not know
+        return name, "FAILED: " + str(e)[-300:].replace("\n", " ")
+
+
+if mode == "build":
+    import multiprocessing as mp
+    with mp.get_context("fork").Pool(4) as pool:
+        for nm, so in pool.imap_unordered(build, list(SETS)):
+            print(nm, so, flush=True)
+else:
+    from tenscalc_amd.runtime import LAYOUT_BATCH_MINOR, HipSolver
+    spec = mk()
+    names = [n for n, _ in spec.parameters + spec.variables]
+    if which == "sls":
+        import torch
+        gen = torch.Generator(device="cuda").manual_seed(1234)
+        dev = {"A": torch.rand((800, B), generator=gen, device="cuda", dtype=torch.float64),
+               "b": torch.rand((100, B), generator=gen, device="cuda", dtype=torch.float64),
+               "x": .02 * torch.rand((8, B), generator=gen, device="cuda", dtype=torch.float64)}
+    else:
+        ds = [data(k) for k in range(min(B, 256))]
+        host = {n: np.stack([np.asarray(ds[k % len(ds)][n], dtype=float).reshape(-1, order="F") for k in range(B)]) for n in names}
+    ref = None
+    for nm in SETS:
+        nm_, so = build(nm)
+        if so.startswith("FAILED"):
+            print(nm, so)
+            continue
+        obj = HipSolver(so, B=B)
+        for n in names:
+            if which == "sls":
+                obj.set_device(n, dev[n], LAYOUT_BATCH_MINOR)
+            else:
+                obj.set(n, host[n])
+        obj.synchronize()
+        ts = []
+        for _ in range(5 if which != "quad" else 2):
+            st, it, tm = obj.solve(**SOLVE_ARGS)
+            ts.append(tm)
+        out = np.concatenate([o.reshape(B, -1) for o in obj.getOutputs()], axis=1)
+        obj.close()
+        if ref is None:
+            ref = (st, it, out)
+        same = np.array_equal(st, ref[0]) and np.array_equal(it, ref[1]) and np.array_equal(out, ref[2], equal_nan=True)
+        print("%s %s B=%d %-14s %.4f ms (median %.4f)  bitwise equal to base: %s" % (which, variant, B, nm, min(ts) * 1e3, np.median(ts) * 1e3, same), flush=True)

@@ -1765,9 +1765,13 @@ def build_class(spec, fp_contract="fast", arch="gfx950", opt="-O3", block=64, fo
                 outdir=None, stats=False, tag=None, extra_flags=(), roll=True, min_waves=0, lanes=1,
                 recip=False, fast_div=False, inline_max=0, reg_budget=150, scratch="auto", body="code",
                 waves=1, fuse=False, static_clean=False, forward=False, rcache=0, lds_state=0, share=False,
-                branch_free_tails=True, exact=False, stg_blocks=0, lds_slots=20000, ilp=False, fw_window=0, sched_every=0):
+                branch_free_tails=True, exact=False, stg_blocks=0, lds_slots=20000, ilp=False, fw_window=0, sched_every=0,
+                try_flags=()):
     """Emit <cls>.hip (+ <cls>.h, <cls>.tape) and compile lib<cls>.so with hipcc for gfx950.
-    Mirrors the createGateway/compile step of cmex2optimizeCS.m:403-417."""
+    Mirrors the createGateway/compile step of cmex2optimizeCS.m:403-417.
+
+    try_flags: compiler flags worth having but not worth failing for (LLVM's experimental scheduling strategies crash
+    the compiler on some classes): tried first, dropped if hipcc fails with them; lib<cls>.flags records what was used."""
     from .tapeio import save_tape, tape_records, _rec
     cls = spec.classname
     outdir = outdir or os.path.join(spec.folder, f"@{cls}")
@@ -1782,7 +1786,7 @@ def build_class(spec, fp_contract="fast", arch="gfx950", opt="-O3", block=64, fo
     kq.update(repr((cls, sorted(spec.defines.items()), [(n, tuple(sz)) for n, sz in spec.outputs], fp_contract, arch, opt, block,
                     stats, tag, tuple(extra_flags), roll, min_waves, lanes, recip, fast_div, inline_max, reg_budget, scratch,
                     body, waves, fuse, static_clean, forward, rcache, lds_state, share, branch_free_tails, exact, stg_blocks,
-                    lds_slots, ilp, fw_window, sched_every, os.environ.get("TC_LDS_PAD_SLOTS", ""),
+                    lds_slots, ilp, fw_window, sched_every, tuple(try_flags), os.environ.get("TC_LDS_PAD_SLOTS", ""),
                     os.environ.get("TC_SWEEP_UNROLL", ""))).encode())
     for f_ in sorted(os.listdir(HERE)):
         if f_.endswith(".py"):
@@ -1817,7 +1821,7 @@ def build_class(spec, fp_contract="fast", arch="gfx950", opt="-O3", block=64, fo
             os.path.join(INCLUDE, "tenscalc_hip.h")]
     # (the digest must not depend on where the tree lies: the libraries built here travel to the GPU box, whose
     # checkout is at another path -- with the include directories hashed in, every library was rebuilt there)
-    h = hashlib.sha256((src + " ".join(f for f in flags if f not in (CSRC, INCLUDE))).encode())
+    h = hashlib.sha256((src + " ".join(f for f in flags + list(try_flags) if f not in (CSRC, INCLUDE))).encode())
     for d in deps:
         h.update(open(d, "rb").read())
     stamp = os.path.join(outdir, f"{cls}{suffix}.stamp")
@@ -1835,10 +1839,17 @@ def build_class(spec, fp_contract="fast", arch="gfx950", opt="-O3", block=64, fo
     write_matlab_class(spec, libname=os.path.basename(so), outdir=outdir)     # @<cls>/<cls>.m
     save_tape(spec.tape, os.path.join(outdir, f"{cls}.tape"))
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-    cmd = [hipcc] + flags + [hip, "-o", so]
+    used = list(try_flags)
+    cmd = [hipcc] + flags + used + [hip, "-o", so]
     r = subprocess.run(cmd, capture_output=True, text=True)
+    if r.returncode and try_flags:
+        used = []
+        cmd = [hipcc] + flags + [hip, "-o", so]
+        r = subprocess.run(cmd, capture_output=True, text=True)
     if r.returncode:
         raise RuntimeError(f"hipcc failed for class {cls}:\n{' '.join(cmd)}\n{r.stdout}\n{r.stderr}")
+    with open(os.path.join(outdir, f"lib{cls}{suffix}.flags"), "w") as f:
+        f.write(" ".join(used) + "\n")
     with open(stamp, "w") as f:
         f.write(digest)
     with open(qfile, "w") as f:
