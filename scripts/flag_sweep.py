@@ -11,10 +11,17 @@ import __graft_entry__ as g
 
 ILP = ("-mllvm", "-amdgpu-sched-strategy=iterative-ilp")
 SETS = {
-    "base": (),
     "iterilp": ILP,
-    "iterilp_novec": ILP + ("-mllvm", "-amdgpu-load-store-vectorizer=0"),
-    "itermaxocc": ("-mllvm", "-amdgpu-sched-strategy=iterative-maxocc"),
+    "aa_sched": ILP + ("-mllvm", "-enable-aa-sched-mi"),
+    "aa_codegen": ILP + ("-mllvm", "-amdgpu-use-aa-in-codegen=1"),
+    "topdown": ILP + ("-mllvm", "-misched-topdown"),
+    "bottomup": ILP + ("-mllvm", "-misched-bottomup"),
+    "cyclic": ILP + ("-mllvm", "-misched-cyclicpath=1"),
+    "bias0": ILP + ("-mllvm", "-amdgpu-schedule-metric-bias=0"),
+    "Os": ILP + ("-Os",),
+    "nolsr": ILP + ("-mllvm", "-disable-lsr"),
+    "postra_bu": ILP + ("-mllvm", "-misched-postra-direction=bottomup"),
+    "postra_bi": ILP + ("-mllvm", "-misched-postra-direction=bidirectional"),
 }
 mode, which, variant, B = sys.argv[1], sys.argv[2], sys.argv[3], int(sys.argv[4])
 if which == "sls":
