@@ -146,6 +146,8 @@ def main():
         if every:
             xch.exchange(pack_results(O, ST, IT))
     if world > 1:
+        if not every:      # one untimed gather: RCCL sets up its channels at the first collective of a kind and size
+            xch.exchange(pack_results(O, ST, IT))
         xch.drain()
     # --- timed region: barrier + synchronize on both sides, exactly K steps
     evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
@@ -404,7 +406,10 @@ def bench_config(args):
     for k in range(args.warmup * P):
         objs[k % P].solve_async(SOLVE["mu0"], SOLVE["maxIter"], ae, stream=streams[k % P].cuda_stream)
     evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
-    if world > 1:
+    if world > 1:      # one untimed gather of the same shape: RCCL sets up its channels at the first collective
+        nout_ = sum(o["numel"] for o in obj.outputs)
+        w_ = torch.zeros((nout_ + 2, B), dtype=torch.float64, device=dev)
+        dist.all_gather_into_tensor(torch.empty((world * (nout_ + 2), B), dtype=torch.float64, device=dev), w_)
         dist.barrier(device_ids=[local])
     torch.cuda.synchronize()
     t0 = time.perf_counter()
