@@ -11,17 +11,10 @@ import __graft_entry__ as g
 
 ILP = ("-mllvm", "-amdgpu-sched-strategy=iterative-ilp")
 SETS = {
+    "base": (),
     "iterilp": ILP,
-    "aa_sched": ILP + ("-mllvm", "-enable-aa-sched-mi"),
-    "aa_codegen": ILP + ("-mllvm", "-amdgpu-use-aa-in-codegen=1"),
-    "topdown": ILP + ("-mllvm", "-misched-topdown"),
-    "bottomup": ILP + ("-mllvm", "-misched-bottomup"),
-    "cyclic": ILP + ("-mllvm", "-misched-cyclicpath=1"),
-    "bias0": ILP + ("-mllvm", "-amdgpu-schedule-metric-bias=0"),
-    "Os": ILP + ("-Os",),
-    "nolsr": ILP + ("-mllvm", "-disable-lsr"),
-    "postra_bu": ILP + ("-mllvm", "-misched-postra-direction=bottomup"),
-    "postra_bi": ILP + ("-mllvm", "-misched-postra-direction=bidirectional"),
+    "iterilp_novec": ILP + ("-mllvm", "-amdgpu-load-store-vectorizer=0"),
+    "itermaxocc": ("-mllvm", "-amdgpu-sched-strategy=iterative-maxocc"),
 }
 mode, which, variant, B = sys.argv[1], sys.argv[2], sys.argv[3], int(sys.argv[4])
 if which == "sls":
@@ -42,6 +35,7 @@ def build(name):
     kw = dict(g.VARIANT_KW[variant])
     kw["tag"] = variant + "_f" + name
     kw["extra_flags"] = SETS[name]
+    kw["try_flags"] = ()          # the variant's own optional flags would blur the comparison
     try:
         return name, mk().build(**kw)
     except Exception as e:      # a flag this compiler does not know
@@ -80,7 +74,7 @@ else:
                 obj.set(n, host[n])
         obj.synchronize()
         ts = []
-        for _ in range(5 if which != "quad" else 2):
+        for _ in range(15 if which != "quad" else 2):
             st, it, tm = obj.solve(**SOLVE_ARGS)
             ts.append(tm)
         out = np.concatenate([o.reshape(B, -1) for o in obj.getOutputs()], axis=1)
