@@ -1,5 +1,5 @@
 """A/B of LDL elimination orders on the GPU box: python scripts/order_ab.py <dcmotor|l1l2|quad> <variant> <B> <order>...
-an order is mindeg | mmdK | depthW.  `--build-only` as last argument compiles the libraries and exits (CPU container)."""
+an order is mindeg | mmdK | mmdK_two | mmdK_allbut1 | depthW.  `--build-only` as last argument compiles the libraries and exits (CPU container)."""
 import os
 import sys
 
@@ -22,8 +22,9 @@ else:
 def order(nm):
     if nm == "mindeg":
         return "mindeg"
-    if nm.startswith("mmd"):
-        return ("mmd", int(nm[3:]))
+    if nm.startswith("mmd"):          # mmd<tolerance>[_<gate>]
+        t, _, gate = nm[3:].partition("_")
+        return ("mmd", int(t), gate) if gate else ("mmd", int(t))
     return ("depth", int(nm[5:]))
 
 

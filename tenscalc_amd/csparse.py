@@ -162,19 +162,22 @@ def min_degree_order(n, rows, cols, stages=None, gate=None):
     return np.array(order, dtype=np.int64)
 
 
-def _gate_one(n, adj, stages):
+def _gate_one(n, adj, stages, eq_gate="one"):
     """(need, gated_by): how many eliminations a node waits for, and who is told when a node goes.  Stage 1 (equality
-    duals, own diagonal -addEye2HessianEq) waits for ONE eliminated stage-0 neighbour, the gate "one" of
-    min_degree_order.  Stage 2 marks the inequality duals (own diagonal -F*lambda): a stage-0 node waits for ALL its
-    stage-2 neighbours, so that a primal variable whose only curvature is the barrier term lambda/F (a slack, a
-    norm's flat direction) never becomes a pivot of size addEye2HessianU before it has received that term."""
+    duals, own diagonal -addEye2HessianEq) waits for eliminated stage-0 neighbours: ONE of them (`eq_gate` "one", the
+    gate of min_degree_order), two ("two"), or all but one ("allbut1") -- the more of them have gone, the more of the
+    Schur complement -G H^-1 G' the pivot has received.  Stage 2 marks the inequality duals (own diagonal
+    -F*lambda): a stage-0 node waits for ALL its stage-2 neighbours, so that a primal variable whose only curvature is
+    the barrier term lambda/F (a slack, a norm's flat direction) never becomes a pivot of size addEye2HessianU before
+    it has received that term."""
     stg = [0] * n if stages is None else [int(s) for s in stages]
     need = [0] * n
     gated_by = [[] for _ in range(n)]
     for i in range(n):
         if stg[i] == 1:
             early = [a for a in adj[i] if stg[a] == 0]
-            need[i] = min(1, len(early))
+            k = len(early)
+            need[i] = {"one": min(1, k), "two": min(2, k), "allbut1": max(min(1, k), k - 1)}[eq_gate]
         elif stg[i] == 0:
             early = [a for a in adj[i] if stg[a] == 2]
             need[i] = len(early)
@@ -185,7 +188,7 @@ def _gate_one(n, adj, stages):
     return need, gated_by
 
 
-def multiple_elimination_order(n, rows, cols, stages=None, slack=0):
+def multiple_elimination_order(n, rows, cols, stages=None, slack=0, eq_gate="one"):
     """Elimination order built in ROUNDS: every round eliminates a maximal independent set of the eligible nodes whose
     degree is within ``slack`` of the current minimum (Liu's multiple minimum degree, with a tolerance).  Nodes of one
     round do not depend on each other, so the elimination tree gets short and bushy: a tridiagonal block is reduced
@@ -197,7 +200,7 @@ def multiple_elimination_order(n, rows, cols, stages=None, slack=0):
         if r != c:
             adj[r].add(c)
             adj[c].add(r)
-    need, gated_by = _gate_one(n, adj, stages)
+    need, gated_by = _gate_one(n, adj, stages, eq_gate)
     seen = [0] * n
     done = [False] * n
     order = []
@@ -786,9 +789,10 @@ class CSparse:
         elif isinstance(how, (tuple, list)) and how[0] == "depth":
             p = depth_aware_order(N, subs[:, 0], subs[:, 1], stages, width=int(how[1]))
         elif isinstance(how, (tuple, list)) and how[0] == "mmd":
-            p = multiple_elimination_order(N, subs[:, 0], subs[:, 1], stages, slack=int(how[1]))
+            p = multiple_elimination_order(N, subs[:, 0], subs[:, 1], stages, slack=int(how[1]),
+                                           eq_gate=how[2] if len(how) > 2 else "one")
         else:
-            raise ValueError("ldl order: 'mindeg', ('depth', width) or ('mmd', slack)")
+            raise ValueError("ldl order: 'mindeg', ('depth', width) or ('mmd', slack[, 'one'|'two'|'allbut1'])")
         pinv = np.empty(N, dtype=np.int64)
         pinv[p] = np.arange(N)
         # permuted lower triangle (row>col) and diagonal: Xp(r,c)=A(p[r],p[c])

@@ -242,13 +242,15 @@ def test_multiple_elimination_order_respects_the_gates():
         if r != c:
             adj[r].add(c)
     for slack in (0, 2, 8):
-        p = multiple_elimination_order(n, rows, cols, stages, slack)
-        assert sorted(p.tolist()) == list(range(n))
-        pos = np.empty(n, dtype=int); pos[p] = np.arange(n)
-        for g in range(nU, nU + nG):
-            assert min(pos[u] for u in adj[g] if u < nU) < pos[g]
-        for u in range(nU):
-            assert all(pos[f] < pos[u] for f in adj[u] if f >= nU + nG)
+        for eq_gate, kmin in (("one", lambda k: 1), ("two", lambda k: min(2, k)), ("allbut1", lambda k: max(1, k - 1))):
+            p = multiple_elimination_order(n, rows, cols, stages, slack, eq_gate=eq_gate)
+            assert sorted(p.tolist()) == list(range(n))
+            pos = np.empty(n, dtype=int); pos[p] = np.arange(n)
+            for g in range(nU, nU + nG):
+                prim = [u for u in adj[g] if u < nU]
+                assert sum(pos[u] < pos[g] for u in prim) >= kmin(len(prim)), (eq_gate, g)
+            for u in range(nU):
+                assert all(pos[f] < pos[u] for f in adj[u] if f >= nU + nG)
 
 
 @pytest.mark.parametrize("order", [("mmd", 0), ("mmd", 3), ("depth", 64)])
