@@ -142,3 +142,29 @@ def test_profiling_view_through_the_boundary(tmp_path):
     assert np.array_equal(res["plain"][0], res["stats"][0]) and np.array_equal(res["plain"][1], res["stats"][1])
     for a, b_ in zip(res["plain"][2], res["stats"][2]):
         assert np.array_equal(a, b_)
+
+
+def test_sls_large_ragged_batch_properties():
+    """sls beyond the benchmark size and not a multiple of anything (B = 150 001, 1.1 GB of inputs): the head of the batch
+    equals the golden vectors bit for bit, replicated instances (k, k + 64 000) are bitwise equal, all converge, the
+    returned x is inside the box"""
+    import __graft_entry__ as g
+    from tenscalc_amd.problems.sls import SOLVE_ARGS, sls_batch
+    from tenscalc_amd.runtime import HipSolver
+    gold = np.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "sls_N100_n8.npz"))
+    n0, per, B = len(gold["seeds"]), 64000, 150001
+    A, b, x0 = sls_batch(per, seed0=int(gold["seeds"][0]))
+    idx = np.arange(B) % per
+    obj = HipSolver(g.sls_spec(g.BENCH_DEFAULT).build(**g.VARIANT_KW[g.BENCH_DEFAULT]), B=B)
+    obj.set("A", np.ascontiguousarray(np.transpose(A, (0, 2, 1)))[idx]); obj.set("b", b[idx]); obj.set("x", x0[idx])
+    st, it, _ = obj.solve(**SOLVE_ARGS)
+    J, x = (o.reshape(B, -1) for o in obj.getOutputs())
+    obj.close()
+    assert (st == 0).all()
+    assert np.array_equal(st[:n0], gold["status"]) and np.array_equal(it[:n0], gold["iter"])
+    assert np.array_equal(J[:n0, 0], gold["J"]) and np.array_equal(x[:n0], gold["x"])
+    for r in (1, 2):
+        k = min(per, B - r * per)
+        assert np.array_equal(it[r * per:r * per + k], it[:k]) and np.array_equal(J[r * per:r * per + k], J[:k])
+        assert np.array_equal(x[r * per:r * per + k], x[:k])
+    assert x.min() > 0 and x.max() < .05
