@@ -987,7 +987,8 @@ def _mask(groups):
 def emit_class(spec, fp_contract="fast", block=64, stats=False, roll=True, min_waves=0, lanes=1,
                recip=False, fast_div=False, inline_max=0, reg_budget=150, scratch="auto", body="code",
                waves=1, fuse=False, static_clean=False, forward=False, rcache=0, lds_state=0, share=False,
-               branch_free_tails=True, exact=False, stg_blocks=0, ilp=False, fw_window=0, sched_every=0):
+               branch_free_tails=True, exact=False, stg_blocks=0, ilp=False, fw_window=0, sched_every=0,
+               refresh_outputs=False):
     """Return the HIP source text of the solver class.
 
     exact=True (lanes>1, fp_contract='off', no recip/fast_div): the wave-cooperative lowering with the
@@ -1305,10 +1306,21 @@ def emit_class(spec, fp_contract="fast", block=64, stats=False, roll=True, min_w
             return f"  TC_EVAL({g});\n"
         return f"  TC_NEED({g});\n"
 
+    # Register families (lane-distributed element families: c.dF*) that getOutputs reads were last written by the push of
+    # the final primal update; kept until then they are live across the whole Newton loop (sls: y = A*x - b, 26
+    # registers of a kernel that spills).  Re-evaluating the pushed groups that DEFINE them right before getOutputs reads
+    # them -- pure functions of the iterate, the same values -- makes them dead in between.
+    fam_groups = {int(T.group[min(f_.members)]) for f_ in L.dfamilies.values()} if (refresh_outputs and lanes > 1) else set()
     for e in T.gets:
         args = ", ".join(f"double *y{k + 1}" for k in range(len(e["outputs"])))
         for sfx in ("", "_full") if elide else ("",):
             w.append(f"static __device__ __forceinline__ void {e['name']}{sfx}(TcCtx &c, {args}) {{\n  TC_UNPACK\n")
+            if e["name"].endswith("_getOutputs") and fam_groups:
+                anc = set()
+                for g in e["parents"]:
+                    anc |= ancestors(g, {g})
+                for g in sorted(fam_groups & anc & set(Dg)):
+                    w.append(f"  TC_CALL_GRP{g};\n")
             for g in e["parents"]:
                 w.append(need(g, e["name"], "x" if not elide else sfx))
             for k, o in enumerate(e["outputs"]):
@@ -1766,7 +1778,7 @@ def build_class(spec, fp_contract="fast", arch="gfx950", opt="-O3", block=64, fo
                 recip=False, fast_div=False, inline_max=0, reg_budget=150, scratch="auto", body="code",
                 waves=1, fuse=False, static_clean=False, forward=False, rcache=0, lds_state=0, share=False,
                 branch_free_tails=True, exact=False, stg_blocks=0, lds_slots=20000, ilp=False, fw_window=0, sched_every=0,
-                try_flags=()):
+                try_flags=(), refresh_outputs=False):
     """Emit <cls>.hip (+ <cls>.h, <cls>.tape) and compile lib<cls>.so with hipcc for gfx950.
     Mirrors the createGateway/compile step of cmex2optimizeCS.m:403-417.
 
@@ -1786,7 +1798,7 @@ def build_class(spec, fp_contract="fast", arch="gfx950", opt="-O3", block=64, fo
     kq.update(repr((cls, sorted(spec.defines.items()), [(n, tuple(sz)) for n, sz in spec.outputs], fp_contract, arch, opt, block,
                     stats, tag, tuple(extra_flags), roll, min_waves, lanes, recip, fast_div, inline_max, reg_budget, scratch,
                     body, waves, fuse, static_clean, forward, rcache, lds_state, share, branch_free_tails, exact, stg_blocks,
-                    lds_slots, ilp, fw_window, sched_every, tuple(try_flags), os.environ.get("TC_LDS_PAD_SLOTS", ""),
+                    lds_slots, ilp, fw_window, sched_every, tuple(try_flags), refresh_outputs, os.environ.get("TC_LDS_PAD_SLOTS", ""),
                     os.environ.get("TC_SWEEP_UNROLL", ""))).encode())
     for f_ in sorted(os.listdir(HERE)):
         if f_.endswith(".py"):
@@ -1810,7 +1822,7 @@ def build_class(spec, fp_contract="fast", arch="gfx950", opt="-O3", block=64, fo
                         reg_budget=reg_budget, scratch=scratch, body=body, waves=waves, fuse=fuse,
                         static_clean=static_clean, forward=forward, rcache=rcache, lds_state=lds_state,
                         share=share, branch_free_tails=branch_free_tails, exact=exact, stg_blocks=stg_blocks, ilp=ilp,
-                        fw_window=fw_window, sched_every=sched_every)
+                        fw_window=fw_window, sched_every=sched_every, refresh_outputs=refresh_outputs)
     hip = os.path.join(outdir, f"{cls}{suffix}.hip")
     so = os.path.join(outdir, f"lib{cls}{suffix}.so")
     flags = [opt, f"--offload-arch={arch}", "-fPIC", "-shared", "-std=c++17",
