@@ -19,7 +19,8 @@ def main(out, rnd, var):
     lines = ["rocprofv3 --kernel-trace --stats summary of: python3 bench.py " + cmdline,
              "Name,Calls,TotalDurationNs,AverageNs,Percentage,MinNs,MaxNs,StdDev"]
     kavg = None
-    for f in glob.glob(os.path.join(out, "kt", "*", "*_kernel_stats.csv")):
+    newest = lambda pat: sorted(glob.glob(pat), key=os.path.getmtime)[-1:]      # noqa: E731  (earlier runs leave their files behind)
+    for f in newest(os.path.join(out, "kt", "*", "*_kernel_stats.csv")):
         for r in csv.DictReader(open(f)):
             nm = r["Name"]
             if len(nm) > 90:
@@ -31,7 +32,7 @@ def main(out, rnd, var):
     pm = {}
     info = {}
     for d in ("pmc_fetch", "pmc_write", "pmc_sq", "pmc_sq2"):
-        for f in glob.glob(os.path.join(out, d, "*", "*_counter_collection.csv")):
+        for f in newest(os.path.join(out, d, "*", "*_counter_collection.csv")):
             agg = collections.defaultdict(list)
             for r in csv.DictReader(open(f)):
                 if r["Kernel_Name"].startswith("tc_solve_kernel"):
