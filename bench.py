@@ -44,12 +44,146 @@ def make_batch(B, rank, dev):
     return A, b, x0
 
 
+def _free_port():
+    import socket
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def launch(args, argv):
+    """`python bench.py --gpus N` with N > 1 and no WORLD_SIZE in the environment: start N FRESH rank processes (one per
+    GPU) through torch.distributed.run and relay rank 0's JSON line.  This parent never touches HIP (no torch.cuda call,
+    no exec of a process that has): the ranks are children, and the parent exits with the launcher's code."""
+    import subprocess
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+           "--master-addr", "127.0.0.1", "--master-port", str(_free_port()), os.path.abspath(__file__)] + list(argv)
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")        # dmabuf IPC: what RCCL needs on this pool
+    env.setdefault("OMP_NUM_THREADS", "1")
+    r = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, text=True)
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{") and '"metric"' in ln]
+    for ln in r.stdout.splitlines():
+        if ln not in lines:
+            print(ln, file=sys.stderr)
+    if lines:
+        print(lines[-1], flush=True)
+    return r.returncode or (0 if lines else 1)
+
+
+class Ranks:
+    """rank / world / device of this process and the process group (RCCL = backend "nccl"; gloo for the rehearsal
+    modes).  TC_BENCH_SINGLE_DEVICE=1: several ranks share GPU 0, collectives through gloo on host copies (RCCL refuses
+    two ranks on one device).  TC_BENCH_STANDIN=1: no GPU at all -- the solver is replaced by a stand-in that produces
+    recognisable results on the CPU, so that launcher, sharding, exchange and reduction can be run end to end where
+    there is no GPU (tests/test_bench_launcher.py); its line is marked and never a measurement."""
+
+    def __init__(self, args, ap):
+        import torch
+        self.rank = int(os.environ.get("RANK", "0"))
+        self.world = int(os.environ.get("WORLD_SIZE", "1"))
+        self.local = int(os.environ.get("LOCAL_RANK", "0"))
+        self.standin = bool(os.environ.get("TC_BENCH_STANDIN"))
+        self.single = bool(os.environ.get("TC_BENCH_SINGLE_DEVICE")) or self.standin
+        if self.world != args.gpus:
+            ap.error("--gpus %d but the launcher started WORLD_SIZE=%d ranks" % (args.gpus, self.world))
+        if self.single:
+            self.local = 0
+        if self.standin:
+            self.dev = self.cdev = torch.device("cpu")
+        else:
+            torch.cuda.set_device(self.local)
+            self.dev = torch.device("cuda", self.local)
+            self.cdev = torch.device("cpu") if self.single else self.dev
+        self.dist = None
+        if self.world > 1:
+            import torch.distributed as dist
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            if self.single:
+                dist.init_process_group(backend="gloo")
+            else:
+                dist.init_process_group(backend="nccl", device_id=self.dev)   # RCCL on ROCm; one rank per GPU
+            self.dist = dist
+            if dist.get_world_size() != self.world:
+                raise SystemExit("bench.py: process group has %d ranks, expected %d" % (dist.get_world_size(), self.world))
+        self.devices = self._device_ids()
+
+    def barrier(self):
+        if self.dist is not None:
+            if self.single:
+                self.dist.barrier()
+            else:
+                self.dist.barrier(device_ids=[self.local])
+
+    def sync(self):
+        if not self.standin:
+            import torch
+            torch.cuda.synchronize()
+
+    def _device_ids(self):
+        """identity of every rank's device, gathered over the process group: n_gpus is what the group SAW, not an echo
+        of WORLD_SIZE"""
+        import socket
+        if self.standin:
+            me = "standin:%d" % self.rank
+        else:
+            import torch
+            pr = torch.cuda.get_device_properties(self.local)
+            ident = getattr(pr, "uuid", None) or getattr(pr, "pci_bus_id", None) or self.local
+            me = "%s:%s" % (socket.gethostname(), ident)
+        if self.dist is None:
+            return [me]
+        got = [None] * self.world
+        self.dist.all_gather_object(got, me)
+        if not self.single and len(set(got)) != self.world:
+            raise SystemExit("bench.py: %d ranks but only %d distinct devices: %s" % (self.world, len(set(got)), got))
+        return got
+
+    def finish(self):
+        if self.dist is not None:
+            self.barrier()
+            self.dist.destroy_process_group()
+
+
+class _StandInSolver:
+    """TC_BENCH_STANDIN only: plays the per-rank solver on the CPU.  Not a solver and not the oracle: `solve` marks every
+    instance whose first input is finite as solved and writes a checksum of its inputs, so that a test can tell which
+    rank produced which column."""
+
+    def __init__(self, B, nout):
+        import torch
+        self.B, self.nout = B, nout
+        self.O = torch.zeros((nout, B), dtype=torch.float64)
+        self.ST = torch.full((B,), -1, dtype=torch.int32)
+        self.IT = torch.zeros((B,), dtype=torch.int32)
+        self.inputs = {}
+
+    def set_device(self, name, t, *a, **k):
+        self.inputs[name] = t
+
+    def solve_async(self, *a, **k):
+        import torch
+        acc = sum(v.reshape(-1, self.B).sum(0) for v in self.inputs.values())
+        self.O[:] = acc
+        self.ST[:] = torch.where(torch.isfinite(acc), 0, 4).to(torch.int32)
+        self.IT[:] = 11
+
+    def close(self):
+        pass
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--batch", type=int, default=0, help="instances per GPU (default: the config's)")
+    ap.add_argument("--batch", type=int, default=0, help="instances per GPU (default: the config's); weak scaling")
+    ap.add_argument("--total", type=int, default=0,
+                    help="STRONG scaling: this many instances in all, contiguous ranges [r*T/N, (r+1)*T/N) per rank "
+                         "(tenscalc_amd/sharding.py:shard_range) -- BASELINE configs[3] (32768 over 8 GPUs) and configs[4] "
+                         "(4096 over 8 GPUs) are stated as totals")
     ap.add_argument("--variant", default=os.environ.get("TC_BENCH_VARIANT", ""),
                     help="w8x (default): 8 lanes/instance wave-cooperative lowering of the REFERENCE tape with the "
                          "reference's arithmetic kept bit for bit (parity class bit-exact: status, iteration count and "
@@ -60,10 +194,14 @@ def main():
                          "CU -- parity class solver-tolerance; w8h / regs / regsl: other lowerings of the hoisted tape")
     ap.add_argument("--cpu-sample", type=int, default=int(os.environ.get("TC_CPU_SAMPLE", "65536")))
     ap.add_argument("--no-cpu", action="store_true")
+    ap.add_argument("--no-configs", action="store_true",
+                    help="default N=1 sls run: do not attach the short runs of BASELINE configs[2..4] under \"configs\"")
+    ap.add_argument("--sustain", type=float, default=2.0,
+                    help="seconds of back-to-back steps after the timed region for `sustained_ms_per_step` (0 = skip)")
     ap.add_argument("--config", default="sls", choices=["sls", "l1l2", "dcmotor", "quadcopter"],
                     help="sls (default): BASELINE.json's metric, configs[1].  The others are BASELINE configs[2..4] in the "
                          "same JSON vocabulary: l1l2 16384 instances, dcmotor 32768 (the whole 8-GPU sweep on one GPU), "
-                         "quadcopter 512 (configs[4]'s per-GPU share of 4096) per GPU; --batch overrides")
+                         "quadcopter 512 (configs[4]'s per-GPU share of 4096) per GPU; --batch / --total override")
     ap.add_argument("--pipeline", type=int, default=1,
                     help="--config runs only: number of batches in flight (that many solver handles, each on a stream of "
                          "its own, steps issued round-robin).  1 (default) = one batched solve after the other.  With >1 the "
@@ -74,38 +212,52 @@ def main():
                     help="N>1: all-gather the results after EVERY step (overlapped with the next solve) instead of once "
                          "after the K steps (SURVEY.md 8e: one gather at the end)")
     args = ap.parse_args()
-    if args.config != "sls":
-        return bench_config(args)
-    args.variant = args.variant or "w8x"
+    if args.gpus < 1:
+        ap.error("--gpus must be >= 1")
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        sys.exit(launch(args, sys.argv[1:]))          # before anything touches the GPU
+    if args.batch and args.total:
+        ap.error("--batch (per GPU, weak scaling) and --total (strong scaling) exclude each other")
     import __graft_entry__ as g
-    sls_variants = [v for v, kw in g.VARIANT_KW.items() if kw.get("body", "code") == "code" and v not in g.CONFIG_ONLY]
-    if args.variant not in sls_variants:
-        ap.error("--variant for --config sls: " + ", ".join(sls_variants))
+    if args.config == "sls":
+        args.variant = args.variant or g.BENCH_DEFAULT
+        sls_variants = [v for v, kw in g.VARIANT_KW.items() if kw.get("body", "code") == "code" and v not in g.CONFIG_ONLY]
+        if args.variant not in sls_variants:
+            ap.error("--variant for --config sls: " + ", ".join(sls_variants))
+    elif args.variant and args.variant not in g.VARIANT_KW:
+        ap.error("--variant for --config %s must be one of: %s" % (args.config, ", ".join(sorted(g.VARIANT_KW))))
+    R = Ranks(args, ap)
+    if args.config == "sls":
+        out = bench_sls(args, R)
+        if (R.rank == 0 and R.world == 1 and not args.no_configs and not R.standin and not args.batch and not args.total
+                and args.variant == g.BENCH_DEFAULT):
+            # BASELINE configs[2..4] ride along in the driver-timed invocation: 3 steps each, bounded CPU samples
+            out["configs"] = {}
+            for name in ("l1l2", "dcmotor", "quadcopter"):
+                t0 = time.perf_counter()
+                try:
+                    sub = argparse.Namespace(**dict(vars(args), config=name, variant="", steps=3, warmup=1, pipeline=1,
+                                                    cpu_budget_s=4.0))
+                    out["configs"][name] = bench_config(sub, R)
+                except Exception as e:        # a side line must not take the headline down with it
+                    out["configs"][name] = {"error": "%s: %s" % (type(e).__name__, e)}
+                out["configs"][name]["wall_s"] = time.perf_counter() - t0
+    else:
+        out = bench_config(args, R)
+    if R.rank == 0:
+        print(json.dumps(out), flush=True)
+    R.finish()
 
+
+def bench_sls(args, R):
+    """BASELINE configs[1]: one step = one tc_solve_kernel launch over this rank's sls instances, inputs resident in
+    HBM.  Returns rank 0's JSON object (None on the other ranks)."""
     import numpy as np
     import torch
-    import torch.distributed as dist
-
-    rank = int(os.environ.get("RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    local = int(os.environ.get("LOCAL_RANK", "0"))
-    single = bool(os.environ.get("TC_BENCH_SINGLE_DEVICE"))
-    if single:   # rehearsal aid: several ranks on ONE GPU. RCCL refuses two ranks on a device, so the
-        local = 0   # collectives go through gloo on host copies; never used for a reported number
-    torch.cuda.set_device(local)
-    dev = torch.device("cuda", local)
-    if world > 1:
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        if single:
-            dist.init_process_group(backend="gloo")
-        else:
-            dist.init_process_group(backend="nccl", device_id=dev)   # RCCL on ROCm; one rank per GPU
-    bar = (lambda: dist.barrier()) if single else (lambda: dist.barrier(device_ids=[local]))
-    cdev = torch.device("cpu") if single else dev
-
     import __graft_entry__ as g
     from tenscalc_amd.problems.sls import SOLVE_ARGS
-    from tenscalc_amd.runtime import LAYOUT_BATCH_MINOR, HipSolver
+    from tenscalc_amd.sharding import ResultExchange, pack_results, reduce_timing, run_timed, shard_range
+    rank, world, dev = R.rank, R.world, R.dev
     spec = g.sls_spec(args.variant)
     kw = dict(g.VARIANT_KW[args.variant])
     if os.environ.get("TC_EXPERIMENT"):          # e.g. TC_EXPERIMENT="min_waves=2,block=256" (tuning runs)
@@ -113,30 +265,49 @@ def main():
             k_, v_ = kv.split("=")
             kw[k_] = int(v_)
         kw["tag"] = (kw.get("tag", "fast") + "_" + os.environ["TC_EXPERIMENT"].replace("=", "").replace(",", "_"))
-    if rank == 0:
-        so = spec.build(**kw)          # prebuilt in-tree normally; compiles here only if missing
-    if world > 1:
-        bar()
-    so = spec.build(**kw)
-
-    B = args.batch or 65536
-    A, b, x0 = make_batch(B, rank, dev)
-    obj = HipSolver(so, B=B, device=local)
-    stream = torch.cuda.current_stream().cuda_stream
-    for nm, t in (("A", A), ("b", b), ("x", x0)):
-        obj.set_device(nm, t, LAYOUT_BATCH_MINOR, stream=stream)
-    torch.cuda.synchronize()
-    optr, sptr, iptr = obj.device_views()
-    O = torch.as_tensor(_DevArray(optr, (9, B), "<f8"), device=dev)
-    ST = torch.as_tensor(_DevArray(sptr, (B,), "<i4"), device=dev)
-    IT = torch.as_tensor(_DevArray(iptr, (B,), "<i4"), device=dev)
-    from tenscalc_amd.sharding import ResultExchange, pack_results, reduce_timing, run_timed
+    if args.total:
+        lo, hi = shard_range(args.total, rank, world)
+        B, Bmax = hi - lo, -(-args.total // world)
+    else:
+        B = Bmax = args.batch or 65536
+    if R.standin:
+        gen = torch.Generator().manual_seed(1234 + rank)
+        A, b, x0 = (torch.rand((n_, B), generator=gen, dtype=torch.float64) for n_ in (800, 100, 8))
+        obj = _StandInSolver(B, 9)
+        O, ST, IT, stream = obj.O, obj.ST, obj.IT, None
+        for nm, t in (("A", A), ("b", b), ("x", x0)):
+            obj.set_device(nm, t)
+    else:
+        from tenscalc_amd.runtime import LAYOUT_BATCH_MINOR, HipSolver
+        if rank == 0:
+            so = spec.build(**kw)          # prebuilt in-tree normally; compiles here only if missing
+        R.barrier()
+        so = spec.build(**kw)
+        A, b, x0 = make_batch(B, rank, dev)
+        obj = HipSolver(so, B=B, device=R.local)
+        stream = torch.cuda.current_stream().cuda_stream
+        for nm, t in (("A", A), ("b", b), ("x", x0)):
+            obj.set_device(nm, t, LAYOUT_BATCH_MINOR, stream=stream)
+        torch.cuda.synchronize()
+        optr, sptr, iptr = obj.device_views()
+        O = torch.as_tensor(_DevArray(optr, (9, B), "<f8"), device=dev)
+        ST = torch.as_tensor(_DevArray(sptr, (B,), "<i4"), device=dev)
+        IT = torch.as_tensor(_DevArray(iptr, (B,), "<i4"), device=dev)
     # the path's only exchange: results (J, x, status, iter) of every rank gathered on every rank -- ONE gather after
     # the K steps by default; with --gather-every-step after every step, overlapped with the next
     # step's solve (packed on the launch stream, the collective asynchronous on RCCL's own stream).  The control
-    # flow is tenscalc_amd/sharding.py:run_timed, rehearsed with gloo on the CPU by tests/test_sharding_gloo.py.
+    # flow is tenscalc_amd/sharding.py:run_timed, rehearsed with gloo on the CPU by tests/test_sharding_gloo.py and
+    # end to end by tests/test_bench_launcher.py.
     every = world > 1 and args.gather_every_step
-    xch = ResultExchange(world, (11, B), cdev) if world > 1 else None
+    xch = ResultExchange(world, (11, Bmax), R.cdev) if world > 1 else None
+
+    def packed():
+        p = pack_results(O, ST, IT)
+        if B < Bmax:        # unequal shards of a --total run: pad to the common width, status -1 = no instance
+            pad = torch.zeros((11, Bmax - B), dtype=p.dtype, device=p.device)
+            pad[9] = -1.0
+            p = torch.cat([p, pad], 1)
+        return p
 
     def solve(_k=0):
         obj.solve_async(SOLVE_ARGS["mu0"], SOLVE_ARGS["maxIter"], SOLVE_ARGS["addEye2Hessian"], stream=stream)
@@ -144,43 +315,63 @@ def main():
     for _ in range(args.warmup):
         solve()
         if every:
-            xch.exchange(pack_results(O, ST, IT))
+            xch.exchange(packed())
     if world > 1:
         if not every:      # one untimed gather: RCCL sets up its channels at the first collective of a kind and size
-            xch.exchange(pack_results(O, ST, IT))
+            xch.exchange(packed())
         xch.drain()
     # --- timed region: barrier + synchronize on both sides, exactly K steps
-    evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
+    evs = [] if R.standin else [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+                                for _ in range(args.steps)]
 
     def step(k):
-        evs[k][0].record()
+        if evs:
+            evs[k][0].record()
         solve()
-        evs[k][1].record()
-    elapsed = run_timed(args.steps, step, lambda: pack_results(O, ST, IT), world, every=every,
-                        barrier=bar, sync=torch.cuda.synchronize, exchange=xch)
-    kern_ms = [a.elapsed_time(b_) for a, b_ in evs]          # events on the launch stream
-    elapsed, solved_per_step = reduce_timing(elapsed, int((ST == 0).sum().item()), world, cdev)   # only status==0 count
+        if evs:
+            evs[k][1].record()
+    elapsed = run_timed(args.steps, step, packed, world, every=every, barrier=R.barrier, sync=R.sync, exchange=xch)
+    kern_ms = [a.elapsed_time(b_) for a, b_ in evs] if evs else [elapsed / args.steps * 1e3]     # events on the launch stream
+    elapsed, solved_per_step = reduce_timing(elapsed, int((ST == 0).sum().item()), world, R.cdev)   # only status==0 count
     value = solved_per_step * args.steps / elapsed
-
+    gathered_ok = None
+    if world > 1:       # what the exchange delivered: every rank's status row, instances counted on rank 0
+        last = xch.last()
+        gathered_ok = int((last[:, 9, :] == 0).sum().item())
+    sustained = None
+    if args.sustain > 0 and world == 1 and not R.standin:
+        # the contract's 20 steps are 24 ms: a second figure over >= args.sustain seconds of back-to-back launches says
+        # whether the clocks hold (same kernel, same inputs, nothing else changed)
+        n_s, t_s = 0, time.perf_counter()
+        while time.perf_counter() - t_s < args.sustain:
+            for _ in range(50):
+                solve()
+            torch.cuda.synchronize()
+            n_s += 50
+        sustained = (time.perf_counter() - t_s) / n_s * 1e3
     out = None
     if rank == 0:
         it = IT.cpu().numpy()
         kavg = float(np.mean(kern_ms)) * 1e-3
         achieved = ALGO_BYTES_PER_SOLVE * B / kavg / 1e9
+        total = args.total or B * world
         out = {
             "metric": "IPM solves/sec (whole node), sls N=100 n=8 batch",
-            "value": value, "unit": "solves/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+            "value": value, "unit": "solves/s", "n_gpus": len(R.devices), "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True,
+            "scaling": "strong" if args.total else "weak",
             "vs_baseline": None, "dtype": "f64", "data": "synthetic",
-            "config": {"workload": "sls box-constrained LS N=100 n=8, batch=%d random (A,b) per GPU, fp64 "
-                                   "(BASELINE.json configs[1])" % B,
-                       "batch_per_gpu": B, "mu0": SOLVE_ARGS["mu0"], "maxIter": SOLVE_ARGS["maxIter"],
+            "config": {"workload": ("sls box-constrained LS N=100 n=8, %s random (A,b), fp64 (BASELINE.json configs[1])"
+                                    % (("batch=%d in all, sharded over %d GPU(s)" % (args.total, world)) if args.total
+                                       else "batch=%d per GPU" % B)),
+                       "batch_per_gpu": B, "batch_total": total, "mu0": SOLVE_ARGS["mu0"], "maxIter": SOLVE_ARGS["maxIter"],
                        "variant": args.variant,
                        "parity_class": g.PARITY_CLASS.get(args.variant, "solver-tolerance"),
                        "tape": ("hoisted (parameter-only contractions first); results within the stated tolerance of the "
                                 "reference tape, tests/test_gpu_parity.py" if args.variant in g.HOISTED else "reference"),
-                       "solved_fraction": solved_per_step / (B * world),
+                       "solved_fraction": solved_per_step / total,
                        "iter_median": float(np.median(it)), "iter_max": int(it.max()),
+                       "devices": R.devices,
                        "sharding": "independent instances per rank; RCCL all_gather of the results only, "
                                    + ("after every step, overlapped with the next solve" if every else "once after the K steps")},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
@@ -188,18 +379,28 @@ def main():
                          "kernel": "tc_solve_kernel", "kernel_ms_avg": kavg * 1e3,
                          "algorithmic_bytes_per_launch": ALGO_BYTES_PER_SOLVE * B,
                          "algorithmic_bytes_per_solve": ALGO_BYTES_PER_SOLVE,
+                         # what actually binds this kernel: dependent fp64 chains at one wavefront per
+                         # SIMD with the per-instance state on chip -- neither HBM nor VALU throughput; "bound" stays
+                         # "hbm" because that is the roofline north_star prices the path against
+                         "binds": "fp64 dependent-issue latency + LDS round trips at 1 wavefront/SIMD (on-chip state); "
+                                  "HBM traffic is 1.05x algorithmic",
                          # this path is sparse scalar fp64 work, so the vector-fp64 fraction is
                          # reported beside the HBM fraction the north star asks for
-                         "fp64_valu": tape_flops(spec, it, B, kavg)},
+                         "fp64_valu": None if R.standin else tape_flops(spec, it, B, kavg)},
         }
-        if not args.no_cpu and world == 1:      # CPU baseline: rank 0 at N=1 only
+        if sustained is not None:
+            out["sustained_ms_per_step"] = sustained
+            out["sustained_value"] = float((ST == 0).sum().item()) / (sustained * 1e-3)
+        if gathered_ok is not None:
+            out["config"]["gathered_solved_last_step"] = gathered_ok
+        if R.standin:
+            out["data"] = "STAND-IN: no solver ran (TC_BENCH_STANDIN rehearsal of the multi-rank control flow)"
+            out["standin"] = True
+        if not args.no_cpu and world == 1 and not R.standin:      # CPU baseline: rank 0 at N=1 only
             # always the reference's own tape (never the hoisted one): that is the path the reference runs
             out["cpu_baseline"] = cpu_baseline(g.sls_spec("strict"), A, b, x0, args.cpu_sample, SOLVE_ARGS)
-        print(json.dumps(out), flush=True)
-    if world > 1:
-        bar()
-        dist.destroy_process_group()
     obj.close()
+    return out
 
 
 FP64_VALU_PEAK_TFLOPS = 78.6       # MI355X_MICROARCH.md: vector fp64 (no MFMA on this path)
@@ -358,59 +559,78 @@ CONFIGS = {
 }
 
 
-def bench_config(args):
-    """python bench.py --config l1l2|dcmotor|quadcopter [--variant V] [--batch B]: one step = one batched solve of B
-    instances per GPU with the inputs resident in HBM; same timing contract and JSON fields as the sls line."""
+def bench_config(args, R):
+    """python bench.py --config l1l2|dcmotor|quadcopter [--variant V] [--batch B | --total T]: one step = one batched
+    solve of this rank's instances with the inputs resident in HBM; same timing contract and JSON fields as the sls line.
+    Every instance of the batch is a distinct draw of the config's data generator (seed = its global instance id), so
+    the iteration-count spread -- what makes a tile or a launch wait for its slowest instance -- is the real one.
+    Returns rank 0's JSON object."""
     import importlib
     import numpy as np
     import torch
-    import torch.distributed as dist
     import __graft_entry__ as g
     from tenscalc_amd.runtime import HipSolver
-    rank = int(os.environ.get("RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    local = int(os.environ.get("LOCAL_RANK", "0"))
-    torch.cuda.set_device(local)
-    dev = torch.device("cuda", local)
-    if world > 1:
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group(backend="nccl", device_id=dev)
+    from tenscalc_amd.sharding import pack_results, reduce_timing, shard_range
+    if R.standin:
+        raise SystemExit("bench.py: TC_BENCH_STANDIN rehearses the sls line only")
+    rank, world, local, dev, dist = R.rank, R.world, R.local, R.dev, R.dist
     modname, mk, datafn, B0, var0, ncpu, label = CONFIGS[args.config]
     mod = importlib.import_module(modname)
     SOLVE = mod.SOLVE_ARGS
+    if args.total:
+        lo, hi = shard_range(args.total, rank, world)
+        B, Bmax = hi - lo, -(-args.total // world)
+    else:
+        B = Bmax = args.batch or B0
+        lo = rank * B
     variant = args.variant or var0                       # any key of __graft_entry__.VARIANT_KW (interp8, ldsm4, strict, ...)
-    if variant not in g.VARIANT_KW:
-        raise SystemExit("bench.py: --variant for --config %s must be one of: %s" % (args.config, ", ".join(sorted(g.VARIANT_KW))))
-    if args.config == "dcmotor" and not args.variant and 0 < args.batch <= 8192:
+    if args.config == "dcmotor" and not args.variant and 0 < Bmax <= 8192:
         variant = "w32x"      # one GPU's share of the 8-GPU sweep: the wave-cooperative lowering (LDS-resident state) wins
-    B = args.batch or B0
     spec = getattr(mod, mk)(folder=g.GENERATED)
     kw = dict(g.VARIANT_KW[variant])
     if rank == 0:
         spec.build(**kw)
-    if world > 1:
-        dist.barrier(device_ids=[local])
+    R.barrier()
     so = spec.build(**kw)
     names = [n for n, _ in spec.parameters + spec.variables]
-    nd = min(B, 256)                                           # 256 distinct seeded instances, tiled over the batch
-    ds = [getattr(mod, datafn)(rank * 256 + k) for k in range(nd)]
-    stacked = {n: np.stack([np.asarray(ds[k % nd][n], dtype=float).reshape(-1, order="F") for k in range(B)]) for n in names}
+    ds = [getattr(mod, datafn)(lo + k) for k in range(B)]                     # distinct instances, seed = global id
+    stacked = {n: np.stack([np.asarray(d[n], dtype=float).reshape(-1, order="F") for d in ds]) for n in names}
+    del ds
     P = max(1, int(args.pipeline))
     objs = [HipSolver(so, B=B, device=local) for _ in range(P)]
     for o_ in objs:
         for n in names:
             o_.set(n, stacked[n])
     obj = objs[0]
-    streams = [torch.cuda.current_stream()] + [torch.cuda.Stream(device=dev) for _ in range(P - 1)]
+    # one torch stream per slot (P == 1: torch's current stream, which is where the kernel events are recorded)
+    streams = [torch.cuda.current_stream()] if P == 1 else [torch.cuda.Stream(device=dev) for _ in range(P)]
     ae = SOLVE.get("addEye2Hessian", (1e-9, 1e-9))
+    nout = sum(o["numel"] for o in obj.outputs)
+    views = []
+    for o_ in objs:
+        optr, sptr, iptr = o_.device_views()
+        views.append((torch.as_tensor(_DevArray(optr, (nout, B), "<f8"), device=dev),
+                      torch.as_tensor(_DevArray(sptr, (B,), "<i4"), device=dev),
+                      torch.as_tensor(_DevArray(iptr, (B,), "<i4"), device=dev)))
+    O, ST, IT = views[(args.steps - 1) % P]           # the handle of the last step
+
+    def packed():
+        p_ = pack_results(O, ST, IT)
+        if B < Bmax:
+            pad = torch.zeros((nout + 2, Bmax - B), dtype=p_.dtype, device=dev)
+            pad[nout] = -1.0
+            p_ = torch.cat([p_, pad], 1)
+        return p_
     for k in range(args.warmup * P):
         objs[k % P].solve_async(SOLVE["mu0"], SOLVE["maxIter"], ae, stream=streams[k % P].cuda_stream)
     evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
+    gathered = None
     if world > 1:      # one untimed gather of the same shape: RCCL sets up its channels at the first collective
-        nout_ = sum(o["numel"] for o in obj.outputs)
-        w_ = torch.zeros((nout_ + 2, B), dtype=torch.float64, device=dev)
-        dist.all_gather_into_tensor(torch.empty((world * (nout_ + 2), B), dtype=torch.float64, device=dev), w_)
-        dist.barrier(device_ids=[local])
+        gathered = torch.empty((world, nout + 2, Bmax), dtype=torch.float64, device=dev)
+        for s_ in streams:
+            torch.cuda.current_stream().wait_stream(s_)
+        dist.all_gather_into_tensor(gathered.view(world * (nout + 2), Bmax), packed().contiguous())
+    R.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for k in range(args.steps):
@@ -418,65 +638,57 @@ def bench_config(args):
         evs[k][0].record(s_)
         objs[k % P].solve_async(SOLVE["mu0"], SOLVE["maxIter"], ae, stream=s_.cuda_stream)
         evs[k][1].record(s_)
-    for s_ in streams[1:]:
-        torch.cuda.current_stream().wait_stream(s_)
-    optr, sptr, iptr = obj.device_views()
-    nout = sum(o["numel"] for o in obj.outputs)
-    ST = torch.as_tensor(_DevArray(sptr, (B,), "<i4"), device=dev)
-    IT = torch.as_tensor(_DevArray(iptr, (B,), "<i4"), device=dev)
+    if P > 1:
+        for s_ in streams:
+            torch.cuda.current_stream().wait_stream(s_)
     if world > 1:      # the path's only exchange: one gather of status / iteration counts / outputs after the K steps
-        O = torch.as_tensor(_DevArray(optr, (nout, B), "<f8"), device=dev)
-        from tenscalc_amd.sharding import pack_results
-        packed = pack_results(O, ST, IT)
-        gathered = torch.empty((world,) + tuple(packed.shape), dtype=packed.dtype, device=dev)
-        dist.all_gather_into_tensor(gathered.view(world * packed.shape[0], B), packed)
+        dist.all_gather_into_tensor(gathered.view(world * (nout + 2), Bmax), packed().contiguous())
     torch.cuda.synchronize()
     if world > 1:
-        dist.barrier(device_ids=[local])
+        R.barrier()
         torch.cuda.synchronize()
     elapsed = time.perf_counter() - t0
-    el = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-    ok = (ST == 0).sum().to(torch.float64).reshape(1)
-    if world > 1:
-        dist.all_reduce(el, op=dist.ReduceOp.MAX)
-        dist.all_reduce(ok, op=dist.ReduceOp.SUM)
-    elapsed = float(el.item())
+    ok_all = [int((v[1] == 0).sum().item()) for v in views[:min(P, args.steps)]]      # status of EVERY handle in flight
+    elapsed, ok = reduce_timing(elapsed, float(np.mean(ok_all)), world, dev)
+    out = None
     if rank == 0:
         it = IT.cpu().numpy()
         st = ST.cpu().numpy()
-        kavg = float(np.mean([a.elapsed_time(b_) for a, b_ in evs])) * 1e-3
         nin = sum(int(np.prod(s_)) if len(s_) else 1 for _, s_ in spec.parameters + spec.variables)
         algo = 8 * (nin + nout) + 8                               # inputs + outputs + (status, iter)
+        if P == 1:
+            kavg = float(np.mean([a.elapsed_time(b_) for a, b_ in evs])) * 1e-3
+            kernel_note = "HIP events around each launch on the launch stream"
+        else:       # spans of overlapping launches include the time spent sharing the chip: use the whole-region rate
+            kavg = elapsed / args.steps
+            kernel_note = "%d batches in flight: elapsed / steps (per-launch event spans overlap and are not reported)" % P
         achieved = algo * B / kavg / 1e9
-        out = {"metric": "IPM solves/sec (whole node), %s batch" % args.config, "value": float(ok.item()) * args.steps / elapsed,
-               "unit": "solves/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-               "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+        total = args.total or B * world
+        out = {"metric": "IPM solves/sec (whole node), %s batch" % args.config, "value": ok * args.steps / elapsed,
+               "unit": "solves/s", "n_gpus": len(R.devices), "steps": args.steps, "warmup": args.warmup,
+               "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True,
+               "scaling": "strong" if args.total else "weak", "vs_baseline": None,
                "dtype": "f64", "data": "synthetic",
-               "config": {"workload": label % B, "batch_per_gpu": B, "mu0": SOLVE["mu0"], "maxIter": SOLVE["maxIter"],
+               "config": {"workload": (label % B) + (" [--total %d sharded over %d GPU(s)]" % (args.total, world) if args.total else ""),
+                          "batch_per_gpu": B, "batch_total": total, "mu0": SOLVE["mu0"], "maxIter": SOLVE["maxIter"],
                           "variant": variant, "parity_class": g.PARITY_CLASS.get(variant, "solver-tolerance"),
-                          "pipeline": P,
-                          "solved_fraction": float(ok.item()) / (B * world), "iter_median": float(np.median(it)),
-                          "iter_max": int(it.max()),
+                          "pipeline": P, "distinct_instances": B,
+                          "solved_fraction": ok / total, "iter_median": float(np.median(it)),
+                          "iter_max": int(it.max()), "devices": R.devices,
                           "sharding": "independent instances per rank; one RCCL all_gather of the results after the K steps"},
                "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                             "frac": achieved / HBM_PEAK_GBPS, "traffic": measured_traffic(args.config + "_" + variant, B),
-                            "kernel": "tc_solve_kernel", "kernel_ms_avg": kavg * 1e3,
+                            "kernel": "tc_solve_kernel", "kernel_ms_avg": kavg * 1e3, "kernel_ms_from": kernel_note,
                             "algorithmic_bytes_per_launch": algo * B, "algorithmic_bytes_per_solve": algo}}
-        if args.config == "quadcopter":      # its tape calls libm pow(): device and glibc differ by 1 ulp on 26 % of arguments
-            out["config"]["parity_note"] = ("the class applies between the device back-ends and to the oracle built with the "
-                                            "same libm; vs the cmex reference 1-iteration agreement 3e-10, "
-                                            "tests/test_gpu_interp.py")
         if not args.no_cpu and world == 1:
-            out["cpu_baseline"] = cpu_baseline_config(spec, args.config, stacked, names, min(B, ncpu), SOLVE, st, it)
-        print(json.dumps(out), flush=True)
-    if world > 1:
-        dist.barrier(device_ids=[local])
-        dist.destroy_process_group()
+            out["cpu_baseline"] = cpu_baseline_config(spec, args.config, stacked, names, min(B, ncpu), SOLVE, st, it,
+                                                      budget_s=getattr(args, "cpu_budget_s", 8.0))
     for o_ in objs:
         o_.close()
+    return out
 
 
-def cpu_baseline_config(spec, which, stacked, names, n, SOLVE, st, it):
+def cpu_baseline_config(spec, which, stacked, names, n, SOLVE, st, it, budget_s=8.0):
     """bounded sample of the same workload on one host core: the generated-C twin where it is prebuilt (dcmotor),
     else the oracle's tape interpreter (the twins of the big tapes are 44 MB C files gcc needs an hour for)"""
     import numpy as np
@@ -502,9 +714,19 @@ def cpu_baseline_config(spec, which, stacked, names, n, SOLVE, st, it):
         run = lambda: o.solve_batch({f"{c}_set_{k}": v for k, v in sub.items()}, c + "_getOutputs", n,      # noqa: E731
                                     mu0=SOLVE["mu0"], maxIter=SOLVE["maxIter"])
         how = "oracle tape interpreter (oracle/tc_oracle.c: same arithmetic as the generated C, about 2-5x slower)"
+    if n > 16:          # pilot: size the sample so that one pass fits the budget (a pass cannot be interrupted)
+        n0 = 8
+        sub0, sub_all = {k: v[:n0] for k, v in sub.items()}, sub
+        sub = sub0
+        t0 = time.perf_counter()
+        nn, n = n, n0
+        run()
+        rate = n0 / max(time.perf_counter() - t0, 1e-6)
+        n = int(min(nn, max(n0, rate * budget_s)))
+        sub = {k: v[:n] for k, v in sub_all.items()}
     t0 = time.perf_counter()
     reps = 0
-    while reps == 0 or (time.perf_counter() - t0 < 8.0 and reps < 64):        # ~10 s of CPU work
+    while reps == 0 or (time.perf_counter() - t0 < budget_s and reps < 64):        # ~10 s of CPU work
         out, st2, it2 = run()
         reps += 1
     dt = (time.perf_counter() - t0) / reps

@@ -38,7 +38,7 @@ def emit_c(spec):
          "#include <math.h>\n#include <float.h>\n#include <stdint.h>\n#include <string.h>\n"
          f"static double m[{max(1, L.nPriv)}];\nstatic double S[{max(1, L.nExt)}];\n"
          f"static unsigned char groupStatus[{T.nGroups + 1}];\n"
-         "#define MM(k) (m[k])\n#define SX(k) (S[k])\n#define TC_DIV(x, d) ((x) / (d))\n#define TC_NUM(x, d) (x)\n"
+         "#define MM(k) (m[k])\n#define SX(k) (S[k])\n#define TC_DIV(x, d) ((x) / (d))\n#define TC_NUM(x, d) (x)\n#define TC_POW_NEG(x, y) pow((x), (y))\n"
          "static inline double tc_min(double a, double x) { return (a > x) ? x : a; }\n"
          "static inline double tc_max(double a, double x) { return (a < x) ? x : a; }\n"
          "static inline double tc_clp(double a, double x, double dx) { if (dx < 0) { const double t = -x / dx; if (a > t) a = t; } return a; }\n"]

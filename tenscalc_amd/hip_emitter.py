@@ -38,8 +38,8 @@ _UNARY = {
     I.I_exp: "exp({0})", I.I_log: "log({0})", I.I_cos: "cos({0})", I.I_minus_cos: "-cos({0})",
     I.I_sin: "sin({0})", I.I_minus_sin: "-sin({0})", I.I_round: "round({0})",
     I.I_ceil: "ceil({0})", I.I_floor: "floor({0})", I.I_abs: "fabs({0})",
-    I.I_sign: "(({0}>=0)?1.0:-1.0)", I.I_sqrt: "sqrt({0})", I.I_Dsqrt: ".5*pow({0},-.5)",
-    I.I_DDsqrt: "-.25*pow({0},-1.5)", I.I_sqr: "{0}*{0}", I.I_2times: "2*{0}", I.I_2: "2.0",
+    I.I_sign: "(({0}>=0)?1.0:-1.0)", I.I_sqrt: "sqrt({0})", I.I_Dsqrt: ".5*TC_POW_NEG({0},-.5)",
+    I.I_DDsqrt: "-.25*TC_POW_NEG({0},-1.5)", I.I_sqr: "{0}*{0}", I.I_2times: "2*{0}", I.I_2: "2.0",
     I.I_cube: "{0}*{0}*{0}", I.I_3sqr: "3*{0}*{0}", I.I_6times: "6*{0}", I.I_atan: "atan({0})",
     I.I_Datan: "1/(1+{0}*{0})", I.I_DDatan: "-2*{0}/(1+{0}*{0})/(1+{0}*{0})",
     I.I_srelu: "log(1+exp({0}))", I.I_dsrelu: "1/(1+exp(-{0}))",
@@ -1164,7 +1164,7 @@ def emit_class(spec, fp_contract="fast", block=64, stats=False, roll=True, min_w
              "// I_clp step: if (dx<0) { t=-x/dx; if (a>t) a=t; }  (instructionsTableUTHash.c:1315-1331)\n"
              "static __device__ __forceinline__ double tc_clp(double a, double x, double dx) {\n"
              "  if (dx < 0) { const double t = -x / dx; if (a > t) a = t; }\n  return a;\n}\n"
-             '#include "tc_wave.hip.inc"\n\n')
+             '#include "tc_wave.hip.inc"\n#include "tc_pow.hip.inc"\n\n')
     # dependency groups ------------------------------------------------------------------
     stream, copy_rng, out_rng = [], {}, None
     if interp:
@@ -1831,7 +1831,9 @@ def build_class(spec, fp_contract="fast", arch="gfx950", opt="-O3", block=64, fo
              f"-ffp-contract={fp_contract}", "-I", CSRC, "-I", INCLUDE, "-Wno-unused-value"] + list(extra_flags)
     deps = [os.path.join(CSRC, "ipm_newton.hip.inc"), os.path.join(CSRC, "tc_runtime.hip.inc"),
             os.path.join(CSRC, "tc_wave.hip.inc"), os.path.join(CSRC, "tc_interp.hip.inc"),
-            os.path.join(CSRC, "tc_ldsm.hip.inc"),
+            os.path.join(CSRC, "tc_ldsm.hip.inc"), os.path.join(CSRC, "tc_pow.hip.inc"),
+            os.path.join(CSRC, "tc_glibcpow.hip.inc"), os.path.join(CSRC, "tc_glibcpow_tables.inc"),
+            os.path.join(CSRC, "tc_crmath.hip.inc"),
             os.path.join(INCLUDE, "tenscalc_hip.h")]
     # (the digest must not depend on where the tree lies: the libraries built here travel to the GPU box, whose
     # checkout is at another path -- with the include directories hashed in, every library was rebuilt there)

@@ -1,0 +1,60 @@
+"""bench.py --gpus N end to end where there is no GPU: the parent starts N fresh rank processes through
+torch.distributed.run, the ranks form a gloo process group, shard the batch (weak: --batch per rank; strong: --total
+through sharding.shard_range), run the K steps with a STAND-IN for the per-rank solver (TC_BENCH_STANDIN: not a solver,
+not the oracle), exchange results once, and rank 0's JSON line comes back through the parent.  What is checked is what
+the driver relies on: n_gpus from the process group, distinct devices, summed solves, max-over-ranks time."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _bench(*argv, env_extra=None, timeout=300):
+    env = dict(os.environ, TC_BENCH_STANDIN="1")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT"):
+        env.pop(k, None)
+    env.update(env_extra or {})
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + [str(a) for a in argv],
+                       capture_output=True, text=True, env=env, timeout=timeout, cwd=ROOT)
+    return r
+
+
+def test_gpus_2_weak_scaling_line(native_built):
+    r = _bench("--gpus", 2, "--steps", 3, "--warmup", 1, "--batch", 64, "--no-cpu")
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1                                  # ONE JSON line, from rank 0
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 2 and d["steps"] == 3 and d["warmup"] == 1 and d["scaling"] == "weak"
+    assert d["standin"] is True and "STAND-IN" in d["data"]
+    assert len(set(d["config"]["devices"])) == 2
+    assert d["config"]["batch_per_gpu"] == 64 and d["config"]["batch_total"] == 128
+    assert d["config"]["solved_fraction"] == 1.0
+    assert d["config"]["gathered_solved_last_step"] == 128          # both ranks' results arrived on rank 0
+    # value = solved instances of ALL ranks * steps / max-over-ranks time
+    assert abs(d["value"] - 128 * 3 / (d["ms_per_step"] * 3e-3)) <= 1e-6 * d["value"]
+
+
+def test_gpus_3_strong_scaling_unequal_shards(native_built):
+    r = _bench("--gpus", 3, "--steps", 2, "--warmup", 1, "--total", 100, "--no-cpu")
+    assert r.returncode == 0, r.stderr[-3000:]
+    d = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
+    assert d["n_gpus"] == 3 and d["scaling"] == "strong"
+    assert d["config"]["batch_total"] == 100 and d["config"]["batch_per_gpu"] == 34       # rank 0 of 34 / 33 / 33
+    assert d["config"]["gathered_solved_last_step"] == 100                                  # padding columns not counted
+    assert d["config"]["solved_fraction"] == 1.0
+
+
+def test_world_size_must_match_gpus(native_built):
+    r = _bench("--gpus", 2, "--steps", 1, "--warmup", 0, "--batch", 8, "--no-cpu",
+               env_extra=dict(WORLD_SIZE="1", RANK="0", LOCAL_RANK="0"))
+    assert r.returncode != 0 and "WORLD_SIZE" in r.stderr
+
+
+def test_default_is_one_gpu_and_batch_total_exclusive(native_built):
+    r = _bench("--batch", 8, "--total", 8)
+    assert r.returncode != 0 and "exclude" in r.stderr

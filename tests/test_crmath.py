@@ -1,0 +1,159 @@
+"""The correctly rounded x^(-1/2), x^(-3/2) of tenscalc_amd/csrc/tc_crmath.hip.inc (device replacement for the
+reference's `.5*pow(x,-.5)` / `-.25*pow(x,-1.5)`, instructionsTableUTHash.c:1418,1424): the host build of the same
+file against exact integer arithmetic, and against the host libm's pow."""
+import ctypes
+import math
+import os
+import subprocess
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+HERE = os.path.join(ROOT, "tests", "crmath")
+
+
+def build_host():
+    out = os.path.join(HERE, "libcrmath_host.so")
+    csrc = os.path.join(ROOT, "tenscalc_amd", "csrc")
+    srcs = [os.path.join(HERE, "crmath_host.c"), os.path.join(csrc, "tc_crmath.hip.inc"),
+            os.path.join(csrc, "tc_glibcpow.hip.inc"), os.path.join(csrc, "tc_glibcpow_tables.inc")]
+    if not os.path.exists(out) or os.path.getmtime(out) < max(map(os.path.getmtime, srcs)):
+        subprocess.run(["gcc", "-O1", "-ffp-contract=off", "-std=gnu99", "-fPIC", "-shared", "-I",
+                        os.path.dirname(srcs[1]), srcs[0], "-o", out, "-lm"], check=True)
+    return ctypes.CDLL(out)
+
+
+def build_dev():
+    """hipcc build of the same files for gfx950 (cross-compiles without a GPU; __graft_entry__.build() calls this)"""
+    out = os.path.join(HERE, "libcrmath_dev.so")
+    csrc = os.path.join(ROOT, "tenscalc_amd", "csrc")
+    srcs = [os.path.join(HERE, "crmath_dev.hip")] + [os.path.join(csrc, f) for f in
+            ("tc_pow.hip.inc", "tc_crmath.hip.inc", "tc_glibcpow.hip.inc", "tc_glibcpow_tables.inc")]
+    if not os.path.exists(out) or os.path.getmtime(out) < max(map(os.path.getmtime, srcs)):
+        subprocess.run([os.environ.get("HIPCC", "/opt/rocm/bin/hipcc"), "-O3", "--offload-arch=gfx950", "-std=c++17",
+                        "-ffp-contract=off", "-fPIC", "-shared", "-I", csrc, srcs[0], "-o", out], check=True)
+    return out
+
+
+def _eval(fn, x):
+    x = np.ascontiguousarray(x, dtype=np.float64)
+    a, b = np.empty_like(x), np.empty_like(x)
+    dp = ctypes.POINTER(ctypes.c_double)
+    fn(x.ctypes.data_as(dp), a.ctypes.data_as(dp), b.ctypes.data_as(dp), ctypes.c_long(x.size))
+    return a, b
+
+
+def exact_power(x, three):
+    """RN(x^(-1/2)) (three=False) or RN(x^(-3/2)) for a positive finite double, by integer arithmetic."""
+    m, e = math.frexp(x)
+    m = int(m * (1 << 53))
+    e -= 53                              # x = m * 2^e exactly
+    if three:
+        m, e = m ** 3, 3 * e
+    K = 260 + (abs(e) // 2 + 2)          # y * 2^K = sqrt(2^(2K) / (m 2^e)) has > 200 significant bits
+    if (2 * K - e) < 0:
+        raise ValueError
+    q = math.isqrt((1 << (2 * K - e)) // m)          # floor; the dropped fraction is far below bit 53
+    nb = q.bit_length()
+    sh = nb - 53
+    hi, rest = q >> sh, q & ((1 << sh) - 1)
+    half = 1 << (sh - 1)
+    assert abs(rest - half) > 4, "too close to a midpoint for this check"
+    if rest > half:
+        hi += 1
+    return math.ldexp(hi, sh - K)
+
+
+def sample(n, seed):
+    r = np.random.RandomState(seed)
+    x = np.concatenate([r.uniform(1e-3, 500, n // 2), np.exp(r.uniform(-60, 60, n // 4)),
+                        r.uniform(0.5, 2.0, n - n // 2 - n // 4)])
+    return x
+
+
+def test_correctly_rounded_against_exact_arithmetic():
+    L = build_host()
+    x = sample(200_000, 1)
+    a, b = _eval(L.crm_eval, x)
+    ea = np.array([exact_power(float(v), False) for v in x])
+    eb = np.array([exact_power(float(v), True) for v in x])
+    assert np.array_equal(a, ea)
+    assert np.array_equal(b, eb)
+
+
+def test_edges_follow_pow():
+    L = build_host()
+    x = np.array([0.0, -0.0, -1.0, np.inf, np.nan, -np.inf, 4.0, 0.25, 2.0 ** -1074, 2.0 ** -1000, 2.0 ** -700,
+                  2.0 ** 700, 2.0 ** 1000, 1.7976931348623157e308, 2.0 ** -1022, 1.0, 2.0 ** 680, 3e-320])
+    a, b = _eval(L.crm_eval, x)
+    pa, pb = _eval(L.libm_eval, x)
+    with np.errstate(all="ignore"):
+        for u, v in ((a, pa), (b, pb)):
+            assert np.array_equal(np.isnan(u), np.isnan(v))
+            ok = ~np.isnan(v)
+            # subnormal results are rounded twice by ours: 1 ulp there
+            assert np.all((u[ok] == v[ok]) | (np.abs(u[ok] - v[ok]) <= np.spacing(np.abs(v[ok])) * (np.abs(v[ok]) < 2.3e-308)))
+    assert a[6] == 0.5 and b[6] == 0.125 and a[7] == 2.0 and b[7] == 8.0
+    # extreme arguments against exact arithmetic
+    for v in (2.0 ** -1000 * 1.37, 2.0 ** -700 * 1.9, 2.0 ** 700 * 1.1, 2.0 ** 1000 * 1.77, 3e-320, 1.7976931348623157e308):
+        a1, b1 = _eval(L.crm_eval, np.array([v]))
+        assert a1[0] == exact_power(v, False)
+        if 2.0 ** -682 < v < 2.0 ** 681:
+            assert b1[0] == exact_power(v, True)
+
+
+def test_host_libm_agrees_except_where_it_misrounds():
+    """glibc's pow is not correctly rounded; wherever it differs from ours, exact arithmetic must side with ours,
+    and the differing fraction is small -- but not small enough for a solve that calls pow 1e4 times, which is why the
+    device restates glibc's algorithm instead (csrc/tc_glibcpow.hip.inc)."""
+    L = build_host()
+    x = sample(2_000_000, 2)
+    a, b = _eval(L.crm_eval, x)
+    pa, pb = _eval(L.libm_eval, x)
+    for ours, libm, three in ((a, pa, False), (b, pb, True)):
+        d = np.nonzero(ours != libm)[0]
+        assert d.size <= 5e-3 * x.size, d.size      # measured: 8e-4 (y=-.5), 4e-3 (y=-1.5)
+        for i in d[:200]:
+            assert ours[i] == exact_power(float(x[i]), three)
+            assert abs(ours[i] - libm[i]) <= np.spacing(abs(ours[i]))
+
+
+def test_host_build_of_the_glibc_restatement_is_the_hosts_pow():
+    """csrc/tc_glibcpow.hip.inc compiled for the host returns the bits of THIS machine's pow(x,-.5), pow(x,-1.5):
+    4e6 ordinary arguments, all binades, subnormal arguments, the special values."""
+    L = build_host()
+    r = np.random.RandomState(7)
+    x = np.concatenate([sample(4_000_000, 4), 2.0 ** r.uniform(-1074, 1023, 200000), 2.0 ** r.uniform(-1074, -1020, 50000),
+                        np.array([0.0, -0.0, -1.0, -3e-320, np.inf, -np.inf, np.nan, 1.0, 4.0, 5e-324, 2.2250738585072014e-308,
+                                  1.7976931348623157e308, 2.0 ** -1000, 2.0 ** -683, 2.0 ** -682, 2.0 ** -340, 2.0 ** 700,
+                                  2.0 ** 716, 2.0 ** 717])])
+    a, b = _eval(L.glibc_emul_eval, x)
+    pa, pb = _eval(L.libm_eval, x)
+    assert np.array_equal(a, pa, equal_nan=True)
+    assert np.array_equal(b, pb, equal_nan=True)
+
+
+@pytest.mark.gpu
+def test_device_pow_is_the_hosts_pow_bit_for_bit():
+    """the device evaluators' TC_POW_NEG (what I_Dsqrt / I_DDsqrt call) == pow() of the GPU box's own libm, and the
+    device build of the correctly rounded pair == its host build"""
+    import torch  # noqa: F401  (one HIP runtime per process)
+    L = build_host()
+    D = ctypes.CDLL(build_dev())
+    r = np.random.RandomState(11)
+    x = np.concatenate([sample(10_000_000, 12), 2.0 ** r.uniform(-1074, 1023, 500000),
+                        np.array([0.0, -0.0, -1.0, np.inf, -np.inf, np.nan, 1.0, 4.0, 5e-324, 2.2250738585072014e-308,
+                                  1.7976931348623157e308, 2.0 ** -1000, 2.0 ** -683, 2.0 ** 700])])
+    dp = ctypes.POINTER(ctypes.c_double)
+    o = [np.empty_like(x) for _ in range(4)]
+    rc = D.crm_dev_eval(x.ctypes.data_as(dp), *[v.ctypes.data_as(dp) for v in o], ctypes.c_long(x.size))
+    assert rc == 0
+    pa, pb = _eval(L.libm_eval, x)
+    ca, cb = _eval(L.crm_eval, x)
+    n1, n2 = int((~((o[0] == pa) | (np.isnan(pa) & np.isnan(o[0])))).sum()), int((~((o[1] == pb) | (np.isnan(pb) & np.isnan(o[1])))).sum())
+    print("\ndevice TC_POW_NEG vs this host's pow on %d arguments: %d / %d mismatches (y=-.5 / y=-1.5); "
+          "correctly rounded pair vs pow: %.2e / %.2e of arguments differ" %
+          (x.size, n1, n2, np.mean(o[2] != pa), np.mean(o[3] != pb)))
+    assert n1 == 0 and n2 == 0
+    assert np.array_equal(o[2], ca, equal_nan=True) and np.array_equal(o[3], cb, equal_nan=True)

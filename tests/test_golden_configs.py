@@ -71,7 +71,7 @@ def test_oracle_reproduces_sls_trace(sls_spec, tape_oracle):
 @pytest.mark.gpu
 @pytest.mark.parametrize("which,tags", [("dcmotor", ["dcmotor_strict", "dcmotor_w32x", "dcmotor_interp", "dcmotor_ldsm4"]),
                                         ("l1l2", ["l1l2_interp", "l1l2_ldsm4"]),
-                                        ("quadcopter", ["quadcopter_ldsm4"])])
+                                        ("quadcopter", ["quadcopter_ldsm4", "quadcopter_ldsm8", "quadcopter_interp"])])
 def test_gpu_reproduces_golden(which, tags):
     import __graft_entry__ as g_
     from tenscalc_amd.runtime import HipSolver
@@ -84,23 +84,17 @@ def test_gpu_reproduces_golden(which, tags):
         obj = HipSolver(libs[tag], B=B, device=0)
         for n in names:
             obj.set(n, st_[n])
-        if which != "quadcopter":
-            st, it, _ = obj.solve(**args)
-            got = np.concatenate([a.reshape(B, -1) for a in obj.getOutputs()], axis=1)
-            assert np.array_equal(st, g["status"]) and np.array_equal(it, g["iter"]), tag
-            assert np.array_equal(got, g["outputs"]), tag
-        else:
+        if which == "quadcopter":
+            # its tape calls pow(x,-.5), pow(x,-1.5); the device evaluates them as the host libm does, bit for bit
+            # (csrc/tc_glibcpow.hip.inc), so the complete solves -- 20..371 Newton iterations on a non-convex
+            # problem -- reproduce the goldens like every other config.  First the outputs after ONE iteration.
             obj.solve(**dict(args, maxIter=1))
             got = np.concatenate([a.reshape(B, -1) for a in obj.getOutputs()], axis=1)
-            ref = g["outputs_maxIter1"]
-            d = np.abs(got - ref) / (1 + np.abs(ref))
-            print("\\nquadcopter after one Newton iteration vs the golden vectors: max |diff|/(1+|ref|) = %.3g" % d.max())
-            assert d.max() <= 1e-8
-            st, it, _ = obj.solve(**args)
-            assert (st == 0).all() and (g["status"] == 0).all()
-            same = it == g["iter"]
-            got = np.concatenate([a.reshape(B, -1) for a in obj.getOutputs()], axis=1)
-            np.testing.assert_allclose(got[same], g["outputs"][same], rtol=1e-6, atol=1e-8)
+            assert np.array_equal(got, g["outputs_maxIter1"]), tag
+        st, it, _ = obj.solve(**args)
+        got = np.concatenate([a.reshape(B, -1) for a in obj.getOutputs()], axis=1)
+        assert np.array_equal(st, g["status"]) and np.array_equal(it, g["iter"]), (tag, it, g["iter"])
+        assert np.array_equal(got, g["outputs"]), tag
         obj.close()
 
 
