@@ -689,17 +689,17 @@ def bench_config(args, R):
 
 
 def cpu_baseline_config(spec, which, stacked, names, n, SOLVE, st, it, budget_s=8.0):
-    """bounded sample of the same workload on one host core: the generated-C twin where it is prebuilt (dcmotor),
-    else the oracle's tape interpreter (the twins of the big tapes are 44 MB C files gcc needs an hour for)"""
+    """bounded sample of the same workload on one host core: the generated-C twin (the tape as reference-style C + the
+    reference's ipmPD_CSsolver.c, gcc -O1; for the big tapes every value in the scratchbook and the group bodies cut
+    into translation units compiled side by side, oracle/c_emitter.py), else the oracle's tape interpreter"""
     import numpy as np
     sub = {k: v[:n] for k, v in stacked.items()}
     twin = None
-    if which == "dcmotor":
-        try:
-            from oracle.c_emitter import CpuTwin
-            twin = CpuTwin(spec)
-        except (FileNotFoundError, OSError):
-            twin = None
+    try:        # prebuilt in the development container for every config (oracle/_ref/lib<cls>_cpu.so)
+        from oracle.c_emitter import CpuTwin
+        twin = CpuTwin(spec)
+    except (FileNotFoundError, OSError):
+        twin = None
     if twin is not None:
         run = lambda: twin.solve_batch(sub, n, mu0=SOLVE["mu0"], maxIter=SOLVE["maxIter"])      # noqa: E731
         how = "generated-C twin + reference ipmPD_CSsolver.c, gcc -O1"

@@ -29,21 +29,70 @@ _DEFINE_NAMES = ["nU", "nG", "nF", "gradTolerance", "addEye2HessianUtolerance", 
                  "smallerNewtonMatrix", "useLDL", "useUmfpack", "allowSave", "debugConvergence", "profiling"]
 
 
-def emit_c(spec):
+FLAT_ABOVE = 20000      # tapes beyond this many instructions: every value in m[], group bodies cut into small
+CHUNK = 256             # functions spread over translation units compiled side by side (gcc -O1 is superlinear in
+                        # the size of a function: l1l2's 54 k instructions as one function per group take an hour)
+
+
+def _prelude(L, T, storage):
+    return ("/* GENERATED CPU twin (oracle/c_emitter.py) -- test infrastructure */\n"
+            "#include <math.h>\n#include <float.h>\n#include <stdint.h>\n#include <string.h>\n"
+            f"{storage} double m[{max(1, L.nPriv)}];\n{storage} double S[{max(1, L.nExt)}];\n"
+            f"{storage} unsigned char groupStatus[{T.nGroups + 1}];\n"
+            "#define MM(k) (m[k])\n#define SX(k) (S[k])\n#define TC_DIV(x, d) ((x) / (d))\n#define TC_NUM(x, d) (x)\n#define TC_POW_NEG(x, y) pow((x), (y))\n"
+            "static inline double tc_min(double a, double x) { return (a > x) ? x : a; }\n"
+            "static inline double tc_max(double a, double x) { return (a < x) ? x : a; }\n"
+            "static inline double tc_clp(double a, double x, double dx) { if (dx < 0) { const double t = -x / dx; if (a > t) a = t; } return a; }\n")
+
+
+def _chunks(body):
+    """cut a group body (flat statements, possibly brace blocks) into pieces of about CHUNK lines at brace depth 0"""
+    out, cur, depth = [], [], 0
+    for ln in body.splitlines(keepends=True):
+        cur.append(ln)
+        depth += ln.count("{") - ln.count("}")
+        if depth == 0 and len(cur) >= CHUNK:
+            out.append("".join(cur))
+            cur = []
+    if cur:
+        out.append("".join(cur))
+    return out
+
+
+def emit_c(spec, flat=None, ntu=16):
+    """-> (main source, input names, input sizes, nOut[, extra translation units when flat])"""
     T = spec.tape
-    L = Lowering(T, getattr(spec, "code", None), roll=True, lanes=1)
-    P = Printer(L, roll=True)
+    if flat is None:
+        flat = T.n > FLAT_ABOVE
+    if flat:
+        L = Lowering(T, None, roll=False, lanes=1, spill_all=True)
+        P = Printer(L, roll=False)
+    else:
+        L = Lowering(T, getattr(spec, "code", None), roll=True, lanes=1)
+        P = Printer(L, roll=True)
     cls = spec.classname
-    w = ["/* GENERATED CPU twin (oracle/c_emitter.py) -- test infrastructure */\n"
-         "#include <math.h>\n#include <float.h>\n#include <stdint.h>\n#include <string.h>\n"
-         f"static double m[{max(1, L.nPriv)}];\nstatic double S[{max(1, L.nExt)}];\n"
-         f"static unsigned char groupStatus[{T.nGroups + 1}];\n"
-         "#define MM(k) (m[k])\n#define SX(k) (S[k])\n#define TC_DIV(x, d) ((x) / (d))\n#define TC_NUM(x, d) (x)\n#define TC_POW_NEG(x, y) pow((x), (y))\n"
-         "static inline double tc_min(double a, double x) { return (a > x) ? x : a; }\n"
-         "static inline double tc_max(double a, double x) { return (a < x) ? x : a; }\n"
-         "static inline double tc_clp(double a, double x, double dx) { if (dx < 0) { const double t = -x / dx; if (a > t) a = t; } return a; }\n"]
+    extra = []
+    if flat:
+        w = [_prelude(L, T, "")]
+        tus = [[_prelude(L, T, "extern")] for _ in range(ntu)]
+        sizes = [0] * ntu
+        for g in range(1, T.nGroups + 1):
+            parts = _chunks(P.group_body(g))
+            for k, part in enumerate(parts):
+                j = sizes.index(min(sizes))
+                tus[j].append(f"void group{g}_{k}(void) {{\n{part}}}\n")
+                sizes[j] += len(part)
+                w.append(f"void group{g}_{k}(void);\n")
+            w.append(f"static void group{g}(void) {{\n" + "".join(f"  group{g}_{k}();\n" for k in range(len(parts))) + "}\n")
+        extra = ["".join(t) for t in tus if len(t) > 1]
+        return _emit_entry_points(spec, T, L, P, cls, w) + (extra,)
+    w = [_prelude(L, T, "static")]
     for g in range(1, T.nGroups + 1):
         w.append(f"static void group{g}(void) {{\n{P.group_body(g)}}}\n")
+    return _emit_entry_points(spec, T, L, P, cls, w) + ([],)
+
+
+def _emit_entry_points(spec, T, L, P, cls, w):
     w.append("#define NEED(g) do { if (!groupStatus[g]) { groupStatus[g] = 1; group##g(); } } while (0)\n")
 
     def inval(ch):
@@ -93,14 +142,14 @@ def build_cpu_twin(spec, opt="-O1"):
     here and no prebuilt library exists"""
     cls = spec.classname
     out = os.path.join(HERE, "_ref", f"lib{cls}_cpu.so")
-    src, names, sizes, nout = emit_c(spec)
+    src, names, sizes, nout, extra = emit_c(spec)
     if not os.path.exists(REF_SOLVER):
         return (out, names, sizes, nout) if os.path.exists(out) else None
     os.makedirs(os.path.join(HERE, "_ref"), exist_ok=True)
     cfile = os.path.join(HERE, "_ref", f"{cls}_cpu.c")
     stamp = cfile + ".stamp"
     import hashlib
-    digest = hashlib.sha256((src + opt).encode()).hexdigest()
+    digest = hashlib.sha256((src + "".join(extra) + opt).encode()).hexdigest()
     if os.path.exists(out) and os.path.exists(stamp) and open(stamp).read() == digest:
         return out, names, sizes, nout
     with open(cfile, "w") as f:
@@ -111,11 +160,31 @@ def build_cpu_twin(spec, opt="-O1"):
     dflags = ["-D%s=%s" % (k, fmt(spec.defines[k])) for k in _DEFINE_NAMES]
     dflags += ["-DverboseLevel=0", "-DEXPORT=", '-DsaveNamePrefix="x"']
     obj = cfile[:-2] + "_loop.o"
-    for cmd in (["gcc", "-w", opt, "-ffp-contract=off", "-std=gnu99", "-fPIC", "-c"] + dflags + [REF_SOLVER, "-o", obj],
-                ["gcc", "-w", opt, "-ffp-contract=off", "-std=gnu99", "-fPIC", "-shared", cfile, obj, "-o", out, "-lm"]):
-        r = subprocess.run(cmd, capture_output=True, text=True)
-        if r.returncode:
-            raise RuntimeError("cpu twin build failed: %s\n%s" % (" ".join(cmd), r.stderr[-3000:]))
+    cc = ["gcc", "-w", opt, "-ffp-contract=off", "-std=gnu99", "-fPIC"]
+    cmds = [cc + ["-c"] + dflags + [REF_SOLVER, "-o", obj]]
+    objs = [obj]
+    for k, tu in enumerate(extra):          # big tapes: the group bodies as translation units compiled side by side
+        tf = cfile[:-2] + f"_tu{k}.c"
+        with open(tf, "w") as f:
+            f.write(tu)
+        cmds.append(cc + ["-c", tf, "-o", tf[:-2] + ".o"])
+        objs.append(tf[:-2] + ".o")
+    jobs = max(1, min(len(cmds), int(os.environ.get("TC_BUILD_JOBS", "0")) or (os.cpu_count() or 1)))
+    running = []
+    for cmd in cmds + [None] * jobs:
+        while running and (cmd is None or len(running) >= jobs):
+            c_, p_ = running.pop(0)
+            _, err = p_.communicate()
+            if p_.returncode:
+                raise RuntimeError("cpu twin build failed: %s\n%s" % (" ".join(c_), err[-3000:]))
+        if cmd is not None:
+            running.append((cmd, subprocess.Popen(cmd, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)))
+    r = subprocess.run(cc + ["-shared", cfile] + objs + ["-o", out, "-lm"], capture_output=True, text=True)
+    if r.returncode:
+        raise RuntimeError("cpu twin link failed:\n%s" % r.stderr[-3000:])
+    for o_ in objs[1:]:
+        os.remove(o_)
+        os.remove(o_[:-2] + ".c")
     os.remove(obj)
     with open(stamp, "w") as f:
         f.write(digest)

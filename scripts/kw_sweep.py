@@ -23,7 +23,7 @@ def build(st):
     kw = dict(g.VARIANT_KW[variant])
     for kv in [x for x in st.split(",") if x]:
         k, v = kv.split("=")
-        kw[k] = int(v)
+        kw[k] = int(v) if v.lstrip('-').isdigit() else v
     kw["tag"] = variant + "_k" + st.replace("=", "").replace(",", "_")
     return st, mk().build(**kw)
 

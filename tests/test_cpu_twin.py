@@ -44,3 +44,19 @@ def test_dcmotor_twin_matches_interpreter(native_built, tmp_path):
     ref, rst, rit = Oracle(tape).solve_batch({f"{c}_set_{n}": stacked[n] for n in names}, c + "_getOutputs", B,
                                              mu0=SOLVE_ARGS["mu0"], maxIter=SOLVE_ARGS["maxIter"])
     assert np.array_equal(out, ref) and np.array_equal(st, rst) and np.array_equal(it, rit)
+
+
+@pytest.mark.parametrize("which", ["l1l2", "quadcopter"])
+def test_big_tape_twins_reproduce_the_goldens(native_built, which):
+    """the twins of the big tapes (every value in the scratchbook, group bodies in translation units compiled side by
+    side) against the golden vectors, which came through the interpreter + the reference's Newton loop"""
+    import os
+    import __graft_entry__ as g
+    from test_golden_configs import GOLD, _problem, _stack
+    spec, data, args = _problem(which, g.GENERATED)
+    tw = _twin(spec)
+    gold = np.load(os.path.join(GOLD, which + ".npz"))
+    names, st_ = _stack(spec, data, gold["seeds"])
+    B = len(gold["seeds"])
+    out, st, it = tw.solve_batch(st_, B, mu0=args["mu0"], maxIter=args["maxIter"])
+    assert np.array_equal(st, gold["status"]) and np.array_equal(it, gold["iter"]) and np.array_equal(out, gold["outputs"])

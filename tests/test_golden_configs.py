@@ -3,7 +3,7 @@ generated through the REFERENCE's own Newton loop by tests/golden/make_golden_co
 
 CPU part: the oracle (restated loop) reproduces every fixture bit for bit -- the fixtures and the checker agree.
 GPU part: the HIP back-ends, called through the C-ABI, reproduce them -- bit for bit for mpc_dcmotor, l1l2 and the
-sls trace; mpc_quadcopter (libm pow, module docstring of tests/test_gpu_interp.py) after one Newton iteration to 1e-8."""
+sls trace, and since round 4 for mpc_quadcopter too (its pow calls are evaluated as the host libm does, csrc/tc_glibcpow.hip.inc)."""
 import os
 
 import numpy as np
