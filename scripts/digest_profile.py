@@ -12,7 +12,7 @@ def main(out, rnd, var):
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     dst = os.path.join(root, "gpurun_out", "profiles_%s" % rnd)
     os.makedirs(dst, exist_ok=True)
-    cmdline = ("--steps 20 --warmup 3 --no-cpu --variant %s" % var) if "_" not in var else \
+    cmdline = ("--steps 20 --warmup 3 --no-cpu --no-configs --sustain 0 --variant %s" % var) if "_" not in var else \
         ("--config %s --variant %s%s --steps %s --warmup 1 --no-cpu" % (tuple(var.split("_", 1)) + (
             (" --batch " + os.environ["TC_PROFILE_BATCH"]) if int(os.environ.get("TC_PROFILE_BATCH", "0")) else "",
             os.environ.get("TC_PROFILE_STEPS", "3"))))
