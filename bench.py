@@ -196,6 +196,8 @@ def main():
     ap.add_argument("--no-cpu", action="store_true")
     ap.add_argument("--no-configs", action="store_true",
                     help="default N=1 sls run: do not attach the short runs of BASELINE configs[2..4] under \"configs\"")
+    ap.add_argument("--per-step-events", action="store_true",
+                    help="sls line: one HIP event pair per launch instead of one pair around the K launches")
     ap.add_argument("--sustain", type=float, default=2.0,
                     help="seconds of back-to-back steps after the timed region for `sustained_ms_per_step` (0 = skip)")
     ap.add_argument("--config", default="sls", choices=["sls", "l1l2", "dcmotor", "quadcopter"],
@@ -321,17 +323,26 @@ def bench_sls(args, R):
             xch.exchange(packed())
         xch.drain()
     # --- timed region: barrier + synchronize on both sides, exactly K steps
+    # kernel time: HIP events on the launch stream over the timed region.  ONE pair around the K launches by default
+    # (average launch duration = span / K, the gaps between launches included): a pair per launch puts two more
+    # packets between consecutive kernels and costs 2-3 % of the step (measured: 1.19 vs 1.14 ms); --per-step-events
+    # restores it (then kernel_ms_avg excludes the gaps)
+    per_step = bool(args.per_step_events)
+    nev = args.steps if per_step else 1
     evs = [] if R.standin else [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
-                                for _ in range(args.steps)]
+                                for _ in range(nev)]
 
     def step(k):
-        if evs:
-            evs[k][0].record()
+        if evs and (per_step or k == 0):
+            evs[k if per_step else 0][0].record()
         solve()
-        if evs:
-            evs[k][1].record()
+        if evs and (per_step or k == args.steps - 1):
+            evs[k if per_step else 0][1].record()
     elapsed = run_timed(args.steps, step, packed, world, every=every, barrier=R.barrier, sync=R.sync, exchange=xch)
-    kern_ms = [a.elapsed_time(b_) for a, b_ in evs] if evs else [elapsed / args.steps * 1e3]     # events on the launch stream
+    if evs:          # events on the launch stream
+        kern_ms = [a.elapsed_time(b_) / (1 if per_step else args.steps) for a, b_ in evs]
+    else:
+        kern_ms = [elapsed / args.steps * 1e3]
     elapsed, solved_per_step = reduce_timing(elapsed, int((ST == 0).sum().item()), world, R.cdev)   # only status==0 count
     value = solved_per_step * args.steps / elapsed
     gathered_ok = None
@@ -377,6 +388,8 @@ def bench_sls(args, R):
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBPS, "traffic": measured_traffic(args.variant, B),
                          "kernel": "tc_solve_kernel", "kernel_ms_avg": kavg * 1e3,
+                         "kernel_ms_from": ("HIP event pair per launch on the launch stream" if per_step else
+                                            "one HIP event pair around the K launches on the launch stream: span / K"),
                          "algorithmic_bytes_per_launch": ALGO_BYTES_PER_SOLVE * B,
                          "algorithmic_bytes_per_solve": ALGO_BYTES_PER_SOLVE,
                          # what actually binds this kernel: dependent fp64 chains at one wavefront per
@@ -730,10 +743,25 @@ def cpu_baseline_config(spec, which, stacked, names, n, SOLVE, st, it, budget_s=
         out, st2, it2 = run()
         reps += 1
     dt = (time.perf_counter() - t0) / reps
-    return {"value": float((st2 == 0).sum()) / dt, "unit": "solves/s", "cores": 1, "kind": "port",
-            "sample": "first %d instances of the benchmark batch, %s, sequential on 1 of %d host cores, %.2f s per pass"
-                      % (n, how, os.cpu_count(), dt),
-            "same_status_iter": bool(np.array_equal(st[:n], st2) and np.array_equal(it[:n], it2))}
+    res = {"value": float((st2 == 0).sum()) / dt, "unit": "solves/s", "cores": 1, "kind": "port",
+           "sample": "first %d instances of the benchmark batch, %s, sequential on 1 of %d host cores, %.2f s per pass"
+                     % (n, how, os.cpu_count(), dt),
+           "same_status_iter": bool(np.array_equal(st[:n], st2) and np.array_equal(it[:n], it2))}
+    if which == "l1l2" and twin is not None:
+        # the GPU class orders the KKT factorisation for a short dependency chain (1.2x the multiply-adds); a CPU would
+        # keep the fill-minimising order: the same sample through the twin of THAT tape, reported beside the first
+        try:
+            import importlib
+            from oracle.c_emitter import CpuTwin
+            import __graft_entry__ as g
+            tw2 = CpuTwin(importlib.import_module("tenscalc_amd.problems.l1l2").l1l2(
+                folder=g.GENERATED, ldlOrder="mindeg", classname="tmpC_minl1l2_mindeg"))
+            t0 = time.perf_counter()
+            _, st3, _ = tw2.solve_batch(sub, n, mu0=SOLVE["mu0"], maxIter=SOLVE["maxIter"])
+            res["value_mindeg_order"] = float((st3 == 0).sum()) / (time.perf_counter() - t0)
+        except (FileNotFoundError, OSError):
+            pass
+    return res
 
 
 if __name__ == "__main__":

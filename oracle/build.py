@@ -10,6 +10,13 @@ import subprocess
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 REF_SOLVER = "/root/reference/lib/ipmPD_CSsolver.c"
+REF_SOLVER_EQ = "/root/reference/lib/ipmPDeq_CSsolver.c"
+# the -D block of the equilibrium solvers (cmex2equilibriumLatentCS.m:417-448)
+EQ_DEFINE_NAMES = ["nZ", "nU", "nD", "nX", "nG", "nF", "nNu", "gradTolerance", "addEye2Hessian1tolerance", "equalTolerance",
+                   "desiredDualityGap", "scaleCost", "scaleInequalities", "scaleEqualities", "alphaMin", "alphaMax",
+                   "coupledAlphas", "setAddEye2Hessian", "adjustAddEye2Hessian", "muFactorAggressive",
+                   "muFactorConservative", "delta", "skipAffine", "smallerNewtonMatrix", "useLDL", "useUmfpack",
+                   "allowSave", "debugConvergence", "debugConvergenceThreshold", "profiling"]
 
 
 def _run(cmd):
@@ -22,11 +29,11 @@ def build_oracle(opt="-O1"):
     """-O1 is the reference's "fastest run-time" setting (examples/l1l2estimationCS.m:22-25).
     -ffp-contract=off: the reference build targets plain x86-64 (no FMA)."""
     out = os.path.join(HERE, "libtc_oracle.so")
-    src = os.path.join(HERE, "tc_oracle.c")
+    srcs = [os.path.join(HERE, "tc_oracle.c"), os.path.join(HERE, "tc_oracle_eq.c")]
     if os.path.exists(out) and os.path.getmtime(out) >= max(
-            os.path.getmtime(src), os.path.getmtime(os.path.join(HERE, "tc_oracle.h"))):
+            [os.path.getmtime(s_) for s_ in srcs] + [os.path.getmtime(os.path.join(HERE, "tc_oracle.h"))]):
         return out
-    _run(["gcc", opt, "-ffp-contract=off", "-std=gnu99", "-fPIC", "-shared", "-I", HERE, src, "-o", out, "-lm"])
+    _run(["gcc", opt, "-ffp-contract=off", "-std=gnu99", "-fPIC", "-shared", "-I", HERE] + srcs + ["-o", out, "-lm"])
     return out
 
 
@@ -36,14 +43,15 @@ def _fmt(v):
     return str(int(v))
 
 
-def build_ref(tag, defines, opt="-O1"):
-    """Compile the reference Newton loop for one problem's #define block; returns the .so path
-    or None when /root/reference is absent (GPU box)."""
+def build_ref(tag, defines, opt="-O1", solver="ipmPD_CSsolver"):
+    """Compile the reference Newton loop (lib/ipmPD_CSsolver.c, or lib/ipmPDeq_CSsolver.c for solver="ipmPDeq_CSsolver")
+    for one problem's #define block; returns the .so path or None when /root/reference is absent (GPU box)."""
     out = os.path.join(HERE, "_ref", "libipmref_%s.so" % tag)
-    if not os.path.exists(REF_SOLVER):
+    ref = REF_SOLVER_EQ if solver == "ipmPDeq_CSsolver" else REF_SOLVER
+    if not os.path.exists(ref):
         return out if os.path.exists(out) else None
     os.makedirs(os.path.join(HERE, "_ref"), exist_ok=True)
-    names = ["nU", "nG", "nF", "gradTolerance", "addEye2HessianUtolerance", "equalTolerance",
+    names = EQ_DEFINE_NAMES if solver == "ipmPDeq_CSsolver" else ["nU", "nG", "nF", "gradTolerance", "addEye2HessianUtolerance", "equalTolerance",
              "desiredDualityGap", "scaleCost", "scaleInequalities", "scaleEqualities", "alphaMin",
              "alphaMax", "coupledAlphas", "setAddEye2Hessian", "adjustAddEye2Hessian", "useInertia",
              "muFactorAggressive", "muFactorConservative", "delta", "skipAffine",
@@ -53,9 +61,10 @@ def build_ref(tag, defines, opt="-O1"):
     dflags += ["-DverboseLevel=0", "-DEXPORT=", '-DsaveNamePrefix="x"']
     obj = out[:-3] + ".o"
     # the -D block only applies to the reference file; the glue and interpreter get none
-    _run(["gcc", "-w", opt, "-ffp-contract=off", "-std=gnu99", "-fPIC", "-c"] + dflags + [REF_SOLVER, "-o", obj])
+    _run(["gcc", "-w", opt, "-ffp-contract=off", "-std=gnu99", "-fPIC", "-c"] + dflags + [ref, "-o", obj])
     _run(["gcc", opt, "-ffp-contract=off", "-std=gnu99", "-fPIC", "-shared", "-I", HERE, obj,
-          os.path.join(HERE, "ref_glue.c"), os.path.join(HERE, "tc_oracle.c"), "-o", out, "-lm"])
+          os.path.join(HERE, "ref_glue.c"), os.path.join(HERE, "tc_oracle.c"), os.path.join(HERE, "tc_oracle_eq.c"),
+          "-o", out, "-lm"])
     os.remove(obj)
     return out
 
@@ -67,23 +76,28 @@ DEFINE_NAMES = ["nU", "nG", "nF", "gradTolerance", "addEye2HessianUtolerance", "
                 "smallerNewtonMatrix", "useLDL", "useUmfpack", "allowSave"]
 
 
-def build_devloop(tag, defines, opt="-O1"):
-    """Host build (g++) of the device Newton loop tenscalc_amd/csrc/ipm_newton.hip.inc over the
-    oracle's tape interpreter (oracle/devloop_glue.cpp), one library per #define block."""
+def build_devloop(tag, defines, opt="-O1", solver="ipmPD_CSsolver"):
+    """Host build (g++) of the device Newton loop tenscalc_amd/csrc/ipm_newton.hip.inc (ipm_newton_eq.hip.inc for
+    solver="ipmPDeq_CSsolver") over the oracle's tape interpreter (oracle/devloop_glue.cpp), one library per #define block."""
     out = os.path.join(HERE, "_ref", "libdevloop_%s.so" % tag)
     os.makedirs(os.path.join(HERE, "_ref"), exist_ok=True)
     csrc = os.path.join(os.path.dirname(HERE), "tenscalc_amd", "csrc")
     obj = out[:-3] + ".o"
     defs = out[:-3] + "_defs.h"
     with open(defs, "w") as f:
-        f.write("".join("#define %s %s\n" % (k, _fmt(defines[k])) for k in DEFINE_NAMES))
-    _run(["g++", "-w", opt, "-ffp-contract=off", "-fPIC", "-c", "-I", HERE, "-I", csrc,
-          '-DTC_DEFINES_H="%s"' % defs, os.path.join(HERE, "devloop_glue.cpp"), "-o", obj])
+        f.write("".join("#define %s %s\n" % (k, _fmt(defines[k]))
+                        for k in (EQ_DEFINE_NAMES if solver == "ipmPDeq_CSsolver" else DEFINE_NAMES)))
+    _run(["g++", "-w", opt, "-ffp-contract=off", "-fPIC", "-c", "-I", HERE, "-I", csrc] +
+         (["-DTC_LOOP_EQ=1"] if solver == "ipmPDeq_CSsolver" else []) +
+         ['-DTC_DEFINES_H="%s"' % defs, os.path.join(HERE, "devloop_glue.cpp"), "-o", obj])
     _run(["gcc", opt, "-ffp-contract=off", "-std=gnu99", "-fPIC", "-c", "-I", HERE,
           os.path.join(HERE, "tc_oracle.c"), "-o", obj[:-2] + "_o.o"])
-    _run(["g++", "-shared", obj, obj[:-2] + "_o.o", "-o", out, "-lm"])
+    _run(["gcc", opt, "-ffp-contract=off", "-std=gnu99", "-fPIC", "-c", "-I", HERE,
+          os.path.join(HERE, "tc_oracle_eq.c"), "-o", obj[:-2] + "_e.o"])
+    _run(["g++", "-shared", obj, obj[:-2] + "_o.o", obj[:-2] + "_e.o", "-o", out, "-lm"])
     os.remove(obj)
     os.remove(obj[:-2] + "_o.o")
+    os.remove(obj[:-2] + "_e.o")
     return out
 
 

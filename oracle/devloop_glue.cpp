@@ -38,12 +38,15 @@ static inline int traced(tco_t *g, const char *name) {
 
 COPY(initPrimal__)
 COPY(initDualEqX__)
+COPY(initDualEq__)
 COPY(initDualIneq__)
 COPY(updatePrimalDual__)
 COPY(scaleIneq__)
 COPY(scaleCost__)
 SET(setAddEye2HessianU__)
 SET(setAddEye2HessianEq__)
+SET(setAddEye2Hessian1__)   /* equilibrium loop, ipmPDeq_CSsolver.c:32-33 */
+SET(setAddEye2Hessian2__)
 SET(setAlphaPrimal__)
 SET(setAlphaDualEq__)
 SET(setAlphaDualIneq__)
@@ -82,15 +85,21 @@ static inline void getHessInertia__(TcCtx &c, double *mp, double *mn) {
   *mn = t[1];
 }
 
-#define TC_POW_HALF(x) sqrt(x)
+#define TC_POW_HALF(x) pow((x), .5)   /* the host libm, as the reference loop calls it */
+#ifdef TC_LOOP_EQ   /* the equilibrium solvers' loop: csrc/ipm_newton_eq.hip.inc <-> lib/ipmPDeq_CSsolver.c */
+#include "ipm_newton_eq.hip.inc"
+#define TC_DEVICE_LOOP ipmPDeq_CSsolver
+#else
 #include "ipm_newton.hip.inc"
+#define TC_DEVICE_LOOP ipmPD_CSsolver
+#endif
 
 extern "C" void tcdev_solve(tco_t *g, double mu0, int maxIter, double ae0, double ae1, int32_t *status,
                             int32_t *iter) {
   TcCtx c = {g};
   int st = 0, it = 0;
   g_ntrace = 0;
-  ipmPD_CSsolver(c, mu0, maxIter, ae0, ae1, &st, &it);
+  TC_DEVICE_LOOP(c, mu0, maxIter, ae0, ae1, &st, &it);
   *status = st;
   *iter = it;
 }

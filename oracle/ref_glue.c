@@ -1,7 +1,7 @@
 /* ORACLE - test infrastructure only.
  *
- * Glue that lets the reference's own Newton loop, /root/reference/lib/ipmPD_CSsolver.c compiled
- * from where it lies, drive the oracle's tape interpreter: it defines the `extern void xxx__()`
+ * Glue that lets the reference's own Newton loops, /root/reference/lib/ipmPD_CSsolver.c and
+ * lib/ipmPDeq_CSsolver.c (equilibrium solvers) compiled from where they lie, drive the oracle's tape interpreter: it defines the `extern void xxx__()`
  * tape entry points that file expects (ipmPD_CSsolver.c:28-51) by forwarding to tc_oracle.c.
  * In the reference these functions are MATLAB-generated code (not producible here: no MATLAB),
  * so this build pins ONLY the Newton-loop control flow of tco_solve(), not tape construction.
@@ -25,6 +25,8 @@ COPY(scaleIneq__)
 COPY(scaleCost__)
 SET(setAddEye2HessianU__)
 SET(setAddEye2HessianEq__)
+SET(setAddEye2Hessian1__)   /* the equilibrium loop's names, ipmPDeq_CSsolver.c:32-33 */
+SET(setAddEye2Hessian2__)
 SET(setAlphaPrimal__)
 SET(setAlphaDualEq__)
 SET(setAlphaDualIneq__)

@@ -257,6 +257,7 @@ void tco_free(tco_t *t) {
 }
 
 const tco_defines_t *tco_defines(const tco_t *t) { return &t->d; }
+double tco_define(const tco_t *t, const char *name, double dflt) { return define(t, name, dflt); }
 int64_t tco_flops(const tco_t *t) { return t->flops; }
 int64_t tco_group_evals(const tco_t *t) { return t->groupEvals; }
 int64_t tco_minF_trials(const tco_t *t) { return t->minFtrials; }

@@ -24,6 +24,7 @@ typedef struct {
 tco_t *tco_load(const char *tapePath);
 void tco_free(tco_t *t);
 const tco_defines_t *tco_defines(const tco_t *t);
+double tco_define(const tco_t *t, const char *name, double dflt);   /* any name of the tape's #define block */
 
 int tco_num_entries(const tco_t *t);
 int tco_entry(const tco_t *t, const char *name);       /* index or -1 */
@@ -42,6 +43,14 @@ void tco_solve(tco_t *t, double mu0, int32_t maxIter, int32_t saveIter,
 void tco_solve_batch(tco_t *t, int nSets, const int *setEntries, const double *const *in, int eOut,
                      double *out, int32_t *status, int32_t *iter, int64_t B, double mu0,
                      int32_t maxIter, const double *addEye2Hessian);
+
+/* ipmPDeq_CSsolver(mu0,maxIter,saveIter,addEye2Hessian,status,iter,time): the equilibrium solvers' loop
+ * (oracle/tc_oracle_eq.c, restating lib/ipmPDeq_CSsolver.c:122-802) */
+void tco_solve_eq(tco_t *t, double mu0, int32_t maxIter, int32_t saveIter,
+                  const double *addEye2Hessian, int32_t *status, int32_t *iter);
+void tco_solve_eq_batch(tco_t *t, int nSets, const int *setEntries, const double *const *in, int eOut,
+                        double *out, int32_t *status, int32_t *iter, int64_t B, double mu0,
+                        int32_t maxIter, const double *addEye2Hessian);
 
 /* introspection for tests */
 double tco_value(const tco_t *t, int64_t instr);

@@ -25,6 +25,10 @@ def _bind(L):
     L.tco_solve_batch.argtypes = [ctypes.c_void_p, ctypes.c_int, ctypes.POINTER(ctypes.c_int),
                                   ctypes.POINTER(_dp), ctypes.c_int, _dp, _i32p, _i32p,
                                   ctypes.c_int64, ctypes.c_double, ctypes.c_int32, _dp]
+    L.tco_solve_eq.argtypes = L.tco_solve.argtypes
+    L.tco_solve_eq_batch.argtypes = L.tco_solve_batch.argtypes
+    L.tco_define.restype = ctypes.c_double
+    L.tco_define.argtypes = [ctypes.c_void_p, ctypes.c_char_p, ctypes.c_double]
     L.tco_value.restype = ctypes.c_double
     L.tco_value.argtypes = [ctypes.c_void_p, ctypes.c_int64]
     for f in ("tco_flops", "tco_group_evals", "tco_minF_trials"):
@@ -42,6 +46,9 @@ class Oracle:
         self.h = ctypes.c_void_p(self.L.tco_load(tape_path.encode()))
         if not self.h:
             raise RuntimeError("cannot load tape " + tape_path)
+        # which Newton loop the tape was generated for: the equilibrium solvers' #define block has nZ
+        # (cmex2equilibriumLatentCS.m:418), the optimisation solvers' has not
+        self.eq = self.L.tco_define(self.h, b"nZ", -1.0) >= 0
 
     def entry(self, name):
         e = self.L.tco_entry(self.h, name.encode())
@@ -69,8 +76,8 @@ class Oracle:
     def solve(self, mu0=1.0, maxIter=200, saveIter=-1, addEye2Hessian=(1e-9, 1e-9)):
         ae = np.array(addEye2Hessian, dtype=np.float64)
         st, it = ctypes.c_int32(0), ctypes.c_int32(0)
-        self.L.tco_solve(self.h, mu0, maxIter, saveIter, ae.ctypes.data_as(_dp),
-                         ctypes.byref(st), ctypes.byref(it))
+        (self.L.tco_solve_eq if self.eq else self.L.tco_solve)(self.h, mu0, maxIter, saveIter, ae.ctypes.data_as(_dp),
+                                                               ctypes.byref(st), ctypes.byref(it))
         return st.value, it.value
 
     def solve_batch(self, sets, out_name, B, mu0=1.0, maxIter=200, addEye2Hessian=(1e-9, 1e-9)):
@@ -87,7 +94,7 @@ class Oracle:
         st = np.zeros(B, dtype=np.int32)
         it = np.zeros(B, dtype=np.int32)
         ae = np.array(addEye2Hessian, dtype=np.float64)
-        self.L.tco_solve_batch(self.h, len(names), ents, ptrs, self.entry(out_name),
+        (self.L.tco_solve_eq_batch if self.eq else self.L.tco_solve_batch)(self.h, len(names), ents, ptrs, self.entry(out_name),
                                out.ctypes.data_as(_dp), st.ctypes.data_as(_i32p),
                                it.ctypes.data_as(_i32p), B, mu0, maxIter, ae.ctypes.data_as(_dp))
         return out, st, it
@@ -110,13 +117,14 @@ class ReferenceLoopOracle(Oracle):
     """Same tape interpreter, but solve() runs the reference's own ipmPD_CSsolver.c
     (oracle/_ref build).  Only available where oracle/_ref/*.so exists."""
 
-    def __init__(self, tape_path, tag, defines):
-        lib = _build.build_ref(tag, defines)
+    def __init__(self, tape_path, tag, defines, solver="ipmPD_CSsolver"):
+        lib = _build.build_ref(tag, defines, solver=solver)
         if lib is None:
             raise FileNotFoundError("oracle/_ref build for %s not available" % tag)
         super().__init__(tape_path, lib=lib)
         self.L.tcref_bind.argtypes = [ctypes.c_void_p]
-        self.L.ipmPD_CSsolver.argtypes = [_dp, _i32p, _i32p, _dp, _i32p, _i32p, _dp]
+        self._loop = getattr(self.L, solver)           # the reference's own symbol
+        self._loop.argtypes = [_dp, _i32p, _i32p, _dp, _i32p, _i32p, _dp]
 
     def solve(self, mu0=1.0, maxIter=200, saveIter=-1, addEye2Hessian=(1e-9, 1e-9)):
         self.L.tcref_bind(self.h)
@@ -124,9 +132,8 @@ class ReferenceLoopOracle(Oracle):
         mi, si = ctypes.c_int32(maxIter), ctypes.c_int32(saveIter)
         ae = np.array(addEye2Hessian, dtype=np.float64)
         st, it, tm = ctypes.c_int32(0), ctypes.c_int32(0), ctypes.c_double(0)
-        self.L.ipmPD_CSsolver(ctypes.byref(mu), ctypes.byref(mi), ctypes.byref(si),
-                              ae.ctypes.data_as(_dp), ctypes.byref(st), ctypes.byref(it),
-                              ctypes.byref(tm))
+        self._loop(ctypes.byref(mu), ctypes.byref(mi), ctypes.byref(si), ae.ctypes.data_as(_dp), ctypes.byref(st),
+                   ctypes.byref(it), ctypes.byref(tm))
         return st.value, it.value
 
 
@@ -134,8 +141,8 @@ class DeviceLoopOracle(Oracle):
     """Same tape interpreter, but solve() runs the DEVICE Newton loop
     (tenscalc_amd/csrc/ipm_newton.hip.inc) compiled for the host by oracle/build.py:build_devloop."""
 
-    def __init__(self, tape_path, tag, defines):
-        lib = _build.build_devloop(tag, defines)
+    def __init__(self, tape_path, tag, defines, solver="ipmPD_CSsolver"):
+        lib = _build.build_devloop(tag, defines, solver=solver)
         super().__init__(tape_path, lib=lib)
         self.L.tcdev_solve.argtypes = [ctypes.c_void_p, ctypes.c_double, ctypes.c_int, ctypes.c_double,
                                        ctypes.c_double, _i32p, _i32p]

@@ -316,6 +316,8 @@ class CSparse:
         self.ldl_perm = {}         # ldl node idx -> permutation (0-based)
         self.ldl_order = None      # None -> module attribute LDL_ORDER
         self.ldl_stats = []
+        self.lu_perm = {}          # lu node idx -> (row permutation, column permutation)
+        self.lu_stats = []
         self._one = None
 
     # ---- declare* API (csparse.m:296-650) --------------------------------------
@@ -883,9 +885,143 @@ class CSparse:
         return (np.vstack([subs[k], np.stack([d, d], 1)]),
                 np.concatenate([ins[k], np.full(N, one, dtype=np.int64)]))
 
+    # ---- LU with row / column orders fixed at code-generation time (@csparse/sparsity_lu.m) ----------
+    def _s_lu(self, n):
+        """Right-looking symbolic Gaussian elimination of A(p,q).  p, q come from a NUMERICAL sparse LU of the matrix
+        filled with "typical" values -- the reference draws 1+.5*rand per distinct instruction (sparsity_lu.m:44-50,
+        MT19937 seed 0) and calls MATLAB's lu(A,.01,'vector') (UMFPACK, :78); here the same random values go through
+        SuperLU (scipy.sparse.linalg.splu, COLAMD, diagonal pivot threshold .01): another fill-reducing order of
+        the same kind, so fill and rounding differ from a MATLAB-generated solver, the algorithm does not.  The
+        symbolic pass then follows sparsity_lu.m:136-195 line by line: in column `col` the pivot is the FIRST remaining
+        row with a structural nonzero (:141-147), every other such row gets a multiplier L = a/pivot (I_div) and its
+        entries right of `col` are updated with I_plus_minus_dot (entry present) or I_minus_dot (fill-in)."""
+        import scipy.sparse as sp
+        from scipy.sparse.linalg import splu
+        A = n.args[0]
+        subs, ins = self.cache[A.idx]
+        N = n.size[0]
+        if len(ins) == 0:
+            raise ValueError("lu: empty matrix")
+        uniq, inv = np.unique(ins, return_inverse=True)
+        vals = (1 + .5 * np.random.RandomState(0).random_sample(len(uniq)))[inv]
+        Atyp = sp.csc_matrix((vals, (subs[:, 0], subs[:, 1])), shape=(N, N))
+        f = splu(Atyp, permc_spec="COLAMD", diag_pivot_thresh=0.01)
+        p = np.argsort(f.perm_r)              # A[p][:, q] = L U
+        q = np.argsort(f.perm_c)
+        pinv = np.empty(N, dtype=np.int64)
+        qinv = np.empty(N, dtype=np.int64)
+        pinv[p] = np.arange(N)
+        qinv[q] = np.arange(N)
+        rows = [dict() for _ in range(N)]      # permuted row -> {permuted col: instr}
+        colrows = [set() for _ in range(N)]
+        tv = [dict() for _ in range(N)]        # typical values alongside (zero-pivot check, :154-156)
+        for (r, c), i, v in zip(subs, ins, vals):
+            pr, pc = int(pinv[r]), int(qinv[c])
+            rows[pr][pc] = int(i)
+            tv[pr][pc] = float(v)
+            colrows[pc].add(pr)
+        t = self.table
+        n0 = len(t)
+        remaining = set(range(N))
+        pp = []
+        for col in range(N):
+            cand = sorted(r for r in colrows[col] if r in remaining)
+            if not cand:
+                raise ValueError("sparsity_lu: no pivot in column %d" % (col + 1))
+            pivot = cand[0]
+            remaining.discard(pivot)
+            pp.append(pivot)
+            if tv[pivot][col] == 0:
+                raise ValueError("lu: unexpected zero pivot")
+            prow = rows[pivot]
+            pcols = sorted(c for c in prow if c > col)
+            for row in cand[1:]:
+                rr = rows[row]
+                tv[row][col] = tv[row][col] / tv[pivot][col]
+                l_ = t.append(I.I_div, [], [rr[col], prow[col]])
+                rr[col] = l_
+                for c in pcols:
+                    if c in rr:
+                        tv[row][c] = tv[row][c] - tv[row][col] * tv[pivot][c]
+                        rr[c] = t.append(I.I_plus_minus_dot, [], [rr[c]] + self._dot_ops([(l_, prow[c])]))
+                    else:
+                        tv[row][c] = -tv[row][col] * tv[pivot][c]
+                        rr[c] = t.append(I.I_minus_dot, [], self._dot_ops([(l_, prow[c])]))
+                        colrows[c].add(row)
+        pp = np.array(pp, dtype=np.int64)
+        S, Ins = [], []
+        for k, r in enumerate(pp):              # row k of L+U is the row that pivoted in column k (:203-204)
+            for c, i in rows[int(r)].items():
+                S.append((k, c))
+                Ins.append(i)
+        self.lu_perm[n.idx] = (p[pp], q)
+        self.lu_stats.append(dict(n=N, nnzA=len(ins), nnzLU=len(Ins), new_instructions=len(t) - n0, tag=n.par[0],
+                                  changed_pivots=int((pp != np.arange(N)).sum())))
+        return _sort_cm(np.array(S, dtype=np.int64).reshape(-1, 2), np.array(Ins, dtype=np.int64), n.size)
+
+    def _mldivide_lu(self, n):
+        """lu(A)\\b = U\\(L\\b(p)) un-permuted by q: unit-lower forward substitution (sparsity_mldivide_l1.m:73-101),
+        backward substitution with the pivots on U's diagonal (sparsity_mldivide_u.m:46-71, :73-74)."""
+        F, b = n.args
+        subs, ins = self.cache[F.idx]
+        p, q = self.lu_perm[F.idx]
+        N = F.size[0]
+        pinv = np.empty(N, dtype=np.int64)
+        pinv[p] = np.arange(N)
+        low = [dict() for _ in range(N)]
+        up = [dict() for _ in range(N)]
+        D = [0] * N
+        for (r, c), i in zip(subs, ins):
+            r, c, i = int(r), int(c), int(i)
+            if r == c:
+                D[r] = i
+            elif r > c:
+                low[r][c] = i
+            else:
+                up[r][c] = i
+        sb, ib = self.cache[b.idx]
+        m = 1 if b.ndim == 1 else b.size[1]
+        cols = [dict() for _ in range(m)]
+        for s_, i in zip(sb, ib):
+            cc = 0 if b.ndim == 1 else int(s_[1])
+            cols[cc][int(pinv[int(s_[0])])] = int(i)
+        t = self.table
+        S, Ins = [], []
+        for cc, X in enumerate(cols):
+            if not X:
+                continue
+            for row in range(1, N):
+                ks = [k for k in low[row] if k in X]
+                if not ks:
+                    continue
+                dots = self._dot_ops([(low[row][k], X[k]) for k in ks])
+                if row in X:
+                    X[row] = t.append(I.I_plus_minus_dot, [], [X[row]] + dots)
+                else:
+                    X[row] = t.append(I.I_minus_dot, [], dots)
+            for row in range(N - 1, -1, -1):
+                if not D[row]:
+                    raise ValueError("mldivide_u: zero in the diagonal")
+                ks = [k for k in up[row] if k in X]
+                if row in X and ks:
+                    X[row] = t.append(I.I_plus_minus_dot_div, [],
+                                      [X[row], D[row]] + self._dot_ops([(up[row][k], X[k]) for k in ks]))
+                elif ks:
+                    X[row] = t.append(I.I_minus_dot_div, [], [D[row]] + self._dot_ops([(up[row][k], X[k]) for k in ks]))
+                elif row in X:
+                    X[row] = t.append(I.I_div, [], [X[row], D[row]])
+            for row, i in X.items():
+                S.append((int(q[row]),) if b.ndim == 1 else (int(q[row]), cc))
+                Ins.append(i)
+        if not S:
+            return _empty(b.ndim)
+        return np.array(S, dtype=np.int64).reshape(-1, b.ndim), np.array(Ins, dtype=np.int64)
+
     # ---- A\b = L'\(D\(L\b(p)))(pinv)  (csparse.m:906-957, sparsity_mldivide_*.m) ----------
     def _s_mldivide(self, n):
         F, b = n.args
+        if F.op == "lu":
+            return self._mldivide_lu(n)
         subs, ins = self.cache[F.idx]
         p = self.ldl_perm[F.idx]
         N = F.size[0]
@@ -999,10 +1135,15 @@ class Tape:
                                       ldl_stats=list(cs.ldl_stats))
 
     @staticmethod
-    def from_instructions(types, opStart, ops, parStart, pars, sets, gets, copies, defines, ldl_stats=()):
+    def from_instructions(types, opStart, ops, parStart, pars, sets, gets, copies, defines, ldl_stats=(), merge=()):
         """Tape from a raw instruction table (CSR arrays, 1-based operand ids) and entry-point lists
         sets=[{name,varname,size,ins,external}], gets=[{name,outputs:[{name,size,ins}]}],
-        copies=[{name,dst,src}]: computes dependency groups, their order, parents/children."""
+        copies=[{name,dst,src}]: computes dependency groups, their order, parents/children.
+
+        merge: lists of instruction ids whose dependency groups are to be ONE group (Tape.merged): the group is needed by
+        whatever needs any of them and invalidated by whatever invalidates any of them -- coarser than the reference's
+        partition (dependencyGroups.m:111-116), never less safe: a group is only ever evaluated more often, on
+        unchanged inputs."""
         T = Tape()
         types = np.asarray(types, dtype=np.int32)
         n = types.size
@@ -1070,10 +1211,19 @@ class Tape:
         # groups: unique (needed-by, depends-on) signatures of computed instructions
         keyof = {}
         group = np.zeros(n + 1, dtype=np.int64)
+        forced = {}
+        for q, members in enumerate(merge, 1):
+            members = [int(i) for i in members if used[int(i)] and not isset[int(i) - 1] and not isload[int(i) - 1]]
+            ks, kd = 0, 0
+            for i in members:
+                ks |= sig[i]
+                kd |= down[i]
+            for i in members:
+                forced[i] = (ks, kd, q)
         for i in range(1, n + 1):
             if not used[i] or isset[i - 1] or isload[i - 1]:
                 continue
-            k = (sig[i], down[i])
+            k = forced.get(i) or (sig[i], down[i])
             g = keyof.get(k)
             if g is None:
                 g = len(keyof) + 1
@@ -1082,6 +1232,39 @@ class Tape:
         # topological order of groups: if g1 uses values of g2 then down(g1)>=down(g2) and
         # up(g2)>=up(g1) with one inclusion strict, so |down|-|up| strictly increases.
         keys = sorted(keyof, key=lambda k: (bin(k[1]).count("1") - bin(k[0]).count("1"), keyof[k]))
+        if merge:
+            # merged groups break the inclusion argument above: order by the dependencies themselves (Kahn, the
+            # candidates taken in the order of the sort above), refusing a merge that closes a cycle
+            import heapq
+            rank = {keyof[k]: r for r, k in enumerate(keys)}
+            preds = {g_: set() for g_ in rank}
+            for i in range(1, n + 1):
+                gi = int(group[i])
+                if gi:
+                    for j in opl[ost[i - 1]:ost[i]]:
+                        gj = int(group[j])
+                        if gj and gj != gi:
+                            preds[gi].add(gj)
+            succs = {g_: set() for g_ in rank}
+            for g_, ps in preds.items():
+                for p_ in ps:
+                    succs[p_].add(g_)
+            indeg = {g_: len(ps) for g_, ps in preds.items()}
+            heap = [(rank[g_], g_) for g_, d_ in indeg.items() if d_ == 0]
+            heapq.heapify(heap)
+            order = []
+            while heap:
+                _, g_ = heapq.heappop(heap)
+                order.append(g_)
+                for s_ in succs[g_]:
+                    indeg[s_] -= 1
+                    if indeg[s_] == 0:
+                        heapq.heappush(heap, (rank[s_], s_))
+            if len(order) != len(rank):
+                raise ValueError("Tape.merged: the merge closes a dependency cycle (a group between the merged ones "
+                                 "must be merged with them)")
+            byid = {keyof[k]: k for k in keys}
+            keys = [byid[g_] for g_ in order]
         remap = {keyof[k]: r + 1 for r, k in enumerate(keys)}
         group = np.array([remap.get(int(g), 0) for g in group], dtype=np.int64)
         T.nGroups = len(keys)
@@ -1119,6 +1302,18 @@ class Tape:
         T.isset, T.isload = isset, isload
         T.flops = T._count_flops()
         return T
+
+    def merged(self, group_sets):
+        """A tape with the same instructions and entry points whose dependency groups `group_sets` (lists of 1-based
+        group numbers of THIS tape) are merged, each list into one group.  Used by the LDS-resident back-end to walk the
+        KKT factorisation and the triangular solves as one level schedule (hip_emitter.emit_class_ldsm, fuse_chain)."""
+        sets = [dict(name=e["name"], varname=e["varname"], size=e["size"], ins=e["ins"], external=e["external"]) for e in self.sets]
+        gets = [dict(name=e["name"], outputs=[dict(name=o["name"], size=o["size"], ins=o["ins"]) for o in e["outputs"]])
+                for e in self.gets]
+        copies = [dict(name=e["name"], dst=e["dst"], src=e["src"]) for e in self.copies]
+        merge = [np.concatenate([self.groups[g_ - 1] for g_ in gs]) for gs in group_sets]
+        return Tape.from_instructions(self.types, self.opStart, self.ops, self.parStart, self.pars, sets, gets, copies,
+                                      self.defines, ldl_stats=self.ldl_stats, merge=merge)
 
     # static flop-class counts per group, same accounting as writeCinstructionsC
     # (instructionsTableUTHash.c:816-832 and the countFlops_* updates in each case)

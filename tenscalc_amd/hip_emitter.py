@@ -59,6 +59,29 @@ def _lit(v):
     return "(" + s + ")" if v < 0 else s
 
 
+def _solver_of(spec):
+    """name of the Newton-loop template the class pastes behind its tape: ipmPD_CSsolver (cmex2optimizeCS.m:95,286) or
+    ipmPDeq_CSsolver (cmex2equilibriumLatentCS.m:401,451)"""
+    return getattr(spec, "solver", "ipmPD_CSsolver")
+
+
+def _define_block(spec):
+    """the solver configuration as the reference's #define block (cmex2optimizeCS.m:303-331,
+    cmex2equilibriumLatentCS.m:417-448): whichever of the known names the class's defines hold"""
+    w = ["// solver configuration (reference: cmex2optimizeCS.m:303-331 / cmex2equilibriumLatentCS.m:417-448)\n"]
+    for k in ["nU", "nG", "nF", "nZ", "nD", "nX", "nNu", "scaleCost", "scaleInequalities", "scaleEqualities", "coupledAlphas",
+              "setAddEye2Hessian", "adjustAddEye2Hessian", "useInertia", "delta", "skipAffine",
+              "smallerNewtonMatrix", "useLDL", "useUmfpack", "allowSave"]:
+        if k in spec.defines:
+            w.append(f"#define {k} {int(spec.defines[k])}\n")
+    for k in ["gradTolerance", "addEye2HessianUtolerance", "addEye2Hessian1tolerance", "equalTolerance", "desiredDualityGap",
+              "alphaMin", "alphaMax", "muFactorAggressive", "muFactorConservative"]:
+        if k in spec.defines:
+            w.append(f"#define {k} {_lit(spec.defines[k])}\n")
+    w.append(f"#define TC_SOLVER_SYMBOL {_solver_of(spec)}\n")
+    return "".join(w)
+
+
 from .lowering import Family, Leaf, Lowering, Node  # noqa: E402
 
 
@@ -1025,6 +1048,14 @@ def emit_class(spec, fp_contract="fast", block=64, stats=False, roll=True, min_w
     computed redundantly by the P lanes on per-instance state held in LDS."""
     T = spec.tape
     interp = body == "interp"
+    eq_solver = _solver_of(spec) == "ipmPDeq_CSsolver"
+    if eq_solver:
+        # the static clean / dirty analysis and the life-time slot sharing restate the call structure of
+        # ipmPD_CSsolver (loop_schedule.newton_program); the equilibrium loop keeps the reference's lazy flags
+        static_clean = False
+        share = False
+        if lanes != 1:
+            raise ValueError("equilibrium classes: one thread per instance (lanes=1) or body='interp' / 'ldsm'")
     if interp:
         if lanes != 1:
             raise ValueError("body='interp' needs lanes=1")
@@ -1064,14 +1095,7 @@ def emit_class(spec, fp_contract="fast", block=64, stats=False, roll=True, min_w
         # phase boundary (one pointer in registers: the least perturbing of the three)
         w.append("#define TC_STATS %d\n" % {"phases": 2, "trace": 3}.get(stats, 1))     # arrays perturb register allocation)
         w.append("#define TC_TRACE_BLOCK %d\n" % int(os.environ.get("TC_TRACE_BLOCK", "0")))
-    w.append("// solver configuration (reference: cmex2optimizeCS.m:303-331)\n")
-    for k in ["nU", "nG", "nF", "scaleCost", "scaleInequalities", "scaleEqualities", "coupledAlphas",
-              "setAddEye2Hessian", "adjustAddEye2Hessian", "useInertia", "delta", "skipAffine",
-              "smallerNewtonMatrix", "useLDL", "useUmfpack", "allowSave"]:
-        w.append(f"#define {k} {int(spec.defines[k])}\n")
-    for k in ["gradTolerance", "addEye2HessianUtolerance", "equalTolerance", "desiredDualityGap",
-              "alphaMin", "alphaMax", "muFactorAggressive", "muFactorConservative"]:
-        w.append(f"#define {k} {_lit(spec.defines[k])}\n")
+    w.append(_define_block(spec))
     nOut = sum(int(np.prod(sz)) if len(sz) else 1 for _, sz in spec.outputs)
     consts = []
     if interp:
@@ -1141,7 +1165,7 @@ def emit_class(spec, fp_contract="fast", block=64, stats=False, roll=True, min_w
              "struct TcCtx {\n  tc_mem m;\n  tc_lds ls;\n  tc_glob S;\n  tc_glob Sd;\n  long B, sdB;\n  int lane;\n"
              "  const __attribute__((address_space(1))) char *Sdb;\n  unsigned sdo8, sdB8;\n"
              "  unsigned long long st[TC_NSTW];\n" + (f"  double rv[{nrv}];\n" if nrv else "") + dmembers +
-             "#if defined(TC_STATS) && TC_STATS == 3\n  __attribute__((address_space(1))) double *trp;\n"
+             "#if defined(TC_STATS) && TC_STATS == 3\n  __attribute__((address_space(1))) double *trp, *trpEnd;   // trace cursor, end of the dbg buffer (stamps stop there)\n"
              "#elif defined(TC_STATS)\n  int nMinF;\n  long long cyc[TC_NGROUPS];\n  int cnt[TC_NGROUPS];\n  long long ph[8], tph;\n#endif\n};\n"
              # input reads are clamped to the input block: every index the emitter prints is in range (constants
              # fold away), the clamp is the backstop for a lane of a split loop that should have been masked
@@ -1203,7 +1227,7 @@ def emit_class(spec, fp_contract="fast", block=64, stats=False, roll=True, min_w
     w.append("\n// TC_EVAL: the group is certainly dirty here (loop_schedule.py): evaluate without testing the flag\n"
              "#define TC_EVAL(g) do { c.st[((g)-1)>>6] |= 1ull << (((g)-1)&63); TC_CALL_GRP##g; } while (0)\n")
     w.append("\n#if defined(TC_STATS) && TC_STATS == 3\n"
-             "#define TC_STAMP(tag) do { if (c.trp) { c.trp[0] = (double)(tag); c.trp[1] = (double)clock64(); c.trp += 2; } } while (0)\n"
+             "#define TC_STAMP(tag) do { if (c.trp && c.trp < c.trpEnd) { c.trp[0] = (double)(tag); c.trp[1] = (double)clock64(); c.trp += 2; } } while (0)\n"
              "#undef TC_EVAL\n"
              "#define TC_EVAL(g) do { c.st[((g)-1)>>6] |= 1ull << (((g)-1)&63); TC_STAMP(g); TC_CALL_GRP##g; TC_STAMP(-(g)); } while (0)\n"
              "#define TC_NEED(g) do { if (!((c.st[((g)-1)>>6] >> (((g)-1)&63)) & 1ull)) { "
@@ -1374,8 +1398,7 @@ def emit_class(spec, fp_contract="fast", block=64, stats=False, roll=True, min_w
                         if L.pslot[int(i)] >= 0})
         w.append("#define TC_LOOP_HEAD_KILL { tc_mem m = c.m; " +
                  " ".join(f"m[{k}] = __builtin_nondeterministic_value(m[{k}]);" for k in slots) + " }\n")
-    w.append("\n#define TC_POW_HALF(x) sqrt(x)\n")
-    w.append(f'#include "ipm_newton.hip.inc"\n\n')
+    w.append('#include "%s"\n\n' % ("ipm_newton_eq.hip.inc" if eq_solver else "ipm_newton.hip.inc"))
     # kernels -------------------------------------------------------------------------------
     outs = T.entry(f"{cls}_getOutputs")[2]["outputs"]
     # common kernel prologue: thread -> (instance, lane), per-instance state, distributed inputs
@@ -1394,6 +1417,7 @@ def emit_class(spec, fp_contract="fast", block=64, stats=False, roll=True, min_w
                 "  for (int k = 0; k < TC_NSTW; k++) c.st[k] = 0;\n"
                 "#if defined(TC_STATS) && TC_STATS == 3\n"
                 "  c.trp = (dbg && blockIdx.x == TC_TRACE_BLOCK && threadIdx.x == 0) ? (__attribute__((address_space(1))) double *)dbg : nullptr;\n"
+                "  c.trpEnd = c.trp ? c.trp + ((long)(2 * TC_NGROUPS + 10) * B - 4) : nullptr;   // the buffer tc_create allocated, minus the end record\n"
                 "  if (c.trp) { c.trp[0] = 1000.0; c.trp[1] = (double)clock64(); c.trp += 2; }\n"
                 "#elif defined(TC_STATS)\n  c.nMinF = 0;\n  for (int k = 0; k < TC_NGROUPS; k++) { c.cyc[k] = 0; c.cnt[k] = 0; }\n"
                 "  for (int k = 0; k < 8; k++) c.ph[k] = 0;\n"
@@ -1428,7 +1452,7 @@ def emit_class(spec, fp_contract="fast", block=64, stats=False, roll=True, min_w
              "                int *__restrict__ status, int *__restrict__ iter, double mu0, int maxIter, double ae0,\n"
              "                double ae1, long B, double *__restrict__ dbg, double *__restrict__ Mg) {\n" + prologue +
              "  int st = 0, it = 0;\n"
-             "  ipmPD_CSsolver(c, mu0, maxIter, ae0, ae1, &st, &it);\n")
+             "  TC_SOLVER_SYMBOL(c, mu0, maxIter, ae0, ae1, &st, &it);\n")
     off = 0
     out_meta = []
     if interp:
@@ -1461,12 +1485,16 @@ def emit_class(spec, fp_contract="fast", block=64, stats=False, roll=True, min_w
     w.append("extern \"C\" __global__ void __launch_bounds__(TC_BLOCK)\n"
              "tc_probe_kernel(const double *__restrict__ S, const double *__restrict__ Sd, double *__restrict__ out,\n"
              "                int which, double mu0, double ae0, double ae1, long B, double *__restrict__ Mg) {\n"
-             "#if defined(TC_STATS) && TC_STATS == 3\n  double *dbg = nullptr;\n#endif\n" + prologue +
-             "#if setAddEye2Hessian != 0\n  setAddEye2HessianU__(c, &ae0);\n  setAddEye2HessianEq__(c, &ae1);\n#endif\n"
-             f"  initPrimal__{full}(c);\n"
-             f"#if scaleCost != 0\n  scaleCost__{full}(c);\n#endif\n"
-             f"#if nF > 0\n#if scaleInequalities != 0\n  scaleIneq__{full}(c);\n#endif\n  setMu__(c, &mu0);\n  initDualIneq__{full}(c);\n#endif\n"
-             f"#if nG > 0\n  initDualEqX__{full}(c);\n#endif\n"
+             "#if defined(TC_STATS) && TC_STATS == 3\n  double *dbg = nullptr;\n#endif\n" + prologue
+             + (("#if setAddEye2Hessian != 0\n  setAddEye2Hessian1__(c, &ae0);\n  setAddEye2Hessian2__(c, &ae1);\n#endif\n"
+                 "  initPrimal__(c);\n#if scaleCost != 0\n  scaleCost__(c);\n#endif\n"
+                 "#if nF > 0\n#if scaleInequalities != 0\n  scaleIneq__(c);\n#endif\n  setMu__(c, &mu0);\n  initDualIneq__(c);\n#endif\n"
+                 "#if nG > 0\n  initDualEq__(c);\n#endif\n") if eq_solver else       # ipmPDeq_CSsolver.c:134-221
+                ("#if setAddEye2Hessian != 0\n  setAddEye2HessianU__(c, &ae0);\n  setAddEye2HessianEq__(c, &ae1);\n#endif\n"
+                 f"  initPrimal__{full}(c);\n"
+                 f"#if scaleCost != 0\n  scaleCost__{full}(c);\n#endif\n"
+                 f"#if nF > 0\n#if scaleInequalities != 0\n  scaleIneq__{full}(c);\n#endif\n  setMu__(c, &mu0);\n  initDualIneq__{full}(c);\n#endif\n"
+                 f"#if nG > 0\n  initDualEqX__{full}(c);\n#endif\n")) +
              "  switch (which) {\n")
     probes = []
     for k, e in enumerate(T.gets if not share else []):     # shared storage has no schedule for a lone get
@@ -1489,11 +1517,20 @@ def emit_class(spec, fp_contract="fast", block=64, stats=False, roll=True, min_w
     return "".join(w), L
 
 
-def emit_class_ldsm(spec, waves=4, stats=False, lds_slots=20000):
+def emit_class_ldsm(spec, waves=4, stats=False, lds_slots=20000, fuse_chain=True):
     """body="ldsm": ONE instance per workgroup of `waves` wavefronts, hot state in LDS, the tape as data whose
     records give every lane a different scalar instruction (csrc/tc_ldsm.hip.inc, ldsm_schedule.py)."""
     from . import ldsm_schedule as lsch
+    if _solver_of(spec) == "ipmPDeq_CSsolver":
+        raise NotImplementedError("body='ldsm' packs the state by life times derived from the call structure of "
+                                  "ipmPD_CSsolver; equilibrium classes: lanes=1 printed code or body='interp'")
     T = spec.tape
+    if fuse_chain and os.environ.get("TC_LDSM_FUSE", "1") != "0":
+        # the factorisation and the substitutions that read it as ONE level schedule (ldsm_schedule.fusion_sets): the
+        # class walks a tape whose dependency groups are coarser than the reference's; values are unchanged
+        fs = lsch.fusion_sets(T)
+        if fs:
+            T = T.merged(fs)
     cls = spec.classname
     W = int(waves)
     cs = lsch.class_stream(T, cls, spec.defines, W=W, lds_slots=lds_slots)
@@ -1511,14 +1548,7 @@ def emit_class_ldsm(spec, waves=4, stats=False, lds_slots=20000):
              f"#define TC_LAUNCH_BOUNDS __launch_bounds__(TC_BLOCK)\n")
     if stats:
         w.append("#define TC_STATS %d\n" % (2 if stats == "phases" else 1))
-    w.append("// solver configuration (reference: cmex2optimizeCS.m:303-331)\n")
-    for k in ["nU", "nG", "nF", "scaleCost", "scaleInequalities", "scaleEqualities", "coupledAlphas",
-              "setAddEye2Hessian", "adjustAddEye2Hessian", "useInertia", "delta", "skipAffine",
-              "smallerNewtonMatrix", "useLDL", "useUmfpack", "allowSave"]:
-        w.append(f"#define {k} {int(spec.defines[k])}\n")
-    for k in ["gradTolerance", "addEye2HessianUtolerance", "equalTolerance", "desiredDualityGap",
-              "alphaMin", "alphaMax", "muFactorAggressive", "muFactorConservative"]:
-        w.append(f"#define {k} {_lit(spec.defines[k])}\n")
+    w.append(_define_block(spec))
     nOut = cs["nOut"]
     w.append(f"#define TC_NM {cs['nLds']}\n#define TC_NMP {cs['nLds']}\n#define TC_NEXT {cs['nExt']}\n#define TC_NOUT {nOut}\n"
              f"#define TC_NGROUPS {T.nGroups}\n#define TC_NSTW {nW}\n\n")
@@ -1618,7 +1648,7 @@ def emit_class_ldsm(spec, waves=4, stats=False, lds_slots=20000):
         w.append(f"static __device__ __forceinline__ void {e['name']}(TcCtx &c) {{\n")
         w.append(need(e["parents"]))
         w.append(f"  tc_ldsm_run(c.m, c.gm, {cs['rid'][e['name']]});\n" + inval(e["children"]) + "}\n")
-    w.append("\n#define TC_POW_HALF(x) sqrt(x)\n#include \"ipm_newton.hip.inc\"\n\n")
+    w.append('\n#include "%s"\n\n' % ("ipm_newton_eq.hip.inc" if _solver_of(spec) == "ipmPDeq_CSsolver" else "ipm_newton.hip.inc"))
     outs = T.entry(f"{cls}_getOutputs")[2]["outputs"]
     gargs = ", ".join("(double *)0" for _ in outs)
     w.append("extern \"C\" __global__ void TC_LAUNCH_BOUNDS\n"
@@ -1635,7 +1665,7 @@ def emit_class_ldsm(spec, waves=4, stats=False, lds_slots=20000):
              "  if (threadIdx.x == 0) c.m[0] = 0.0;\n"
              "  __syncthreads();\n"
              "  int st = 0, it = 0;\n"
-             "  ipmPD_CSsolver(c, mu0, maxIter, ae0, ae1, &st, &it);\n"
+             "  TC_SOLVER_SYMBOL(c, mu0, maxIter, ae0, ae1, &st, &it);\n"
              f"  {cls}_getOutputs(c, {gargs});\n"
              f"  for (int j = threadIdx.x; j < TC_NOUT; j += TC_BLOCK) {{ const int a = tc_code[{cs['out_off']} + j]; "
              "O[(long)j * B + tid] = TCL_LD(a); }\n"
@@ -1768,7 +1798,7 @@ def class_header(spec):
          "#ifdef __cplusplus\nextern \"C\" {\n#endif\n")
     for nm, _ in spec.parameters + spec.variables:
         s += f"void {cls}_set_{nm}(const double *input);\n"
-    s += ("void ipmPD_CSsolver(double *mu0, int32_t *maxIter, int32_t *saveIter, double *addEye2Hessian,\n"
+    s += (f"void {_solver_of(spec)}(double *mu0, int32_t *maxIter, int32_t *saveIter, double *addEye2Hessian,\n"
           "                    int32_t *status, int32_t *iter, double *time);\n")
     s += f"void {cls}_getOutputs(" + ", ".join(f"double *y{k + 1}" for k in range(len(spec.outputs))) + ");\n"
     s += "#ifdef __cplusplus\n}\n#endif\n"
@@ -1800,7 +1830,7 @@ def build_class(spec, fp_contract="fast", arch="gfx950", opt="-O3", block=64, fo
     kq.update(repr((cls, sorted(spec.defines.items()), [(n, tuple(sz)) for n, sz in spec.outputs], fp_contract, arch, opt, block,
                     stats, tag, tuple(extra_flags), roll, min_waves, lanes, recip, fast_div, inline_max, reg_budget, scratch,
                     body, waves, fuse, static_clean, forward, rcache, lds_state, share, branch_free_tails, exact, stg_blocks,
-                    lds_slots, ilp, fw_window, sched_every, tuple(try_flags), refresh_outputs, os.environ.get("TC_LDS_PAD_SLOTS", ""), os.environ.get("TC_STG_BATCH", ""),
+                    lds_slots, ilp, fw_window, sched_every, tuple(try_flags), refresh_outputs, os.environ.get("TC_LDS_PAD_SLOTS", ""), os.environ.get("TC_STG_BATCH", ""), os.environ.get("TC_LDSM_FUSE", ""),
                     os.environ.get("TC_SWEEP_UNROLL", ""))).encode())
     for f_ in sorted(os.listdir(HERE)):
         if f_.endswith(".py"):
@@ -1817,7 +1847,7 @@ def build_class(spec, fp_contract="fast", arch="gfx950", opt="-O3", block=64, fo
     if body == "ldsm":
         if fp_contract != "off":
             raise ValueError("body='ldsm' is a bit-exact back-end: fp_contract='off'")
-        src, L = emit_class_ldsm(spec, waves=waves, stats=stats, lds_slots=lds_slots)
+        src, L = emit_class_ldsm(spec, waves=waves, stats=stats, lds_slots=lds_slots)      # TC_LDSM_FUSE=0: no fused walk
     else:
       src, L = emit_class(spec, fp_contract=fp_contract, block=block, stats=stats, roll=roll,
                         min_waves=min_waves, lanes=lanes, recip=recip, fast_div=fast_div, inline_max=inline_max,
@@ -1829,7 +1859,8 @@ def build_class(spec, fp_contract="fast", arch="gfx950", opt="-O3", block=64, fo
     so = os.path.join(outdir, f"lib{cls}{suffix}.so")
     flags = [opt, f"--offload-arch={arch}", "-fPIC", "-shared", "-std=c++17",
              f"-ffp-contract={fp_contract}", "-I", CSRC, "-I", INCLUDE, "-Wno-unused-value"] + list(extra_flags)
-    deps = [os.path.join(CSRC, "ipm_newton.hip.inc"), os.path.join(CSRC, "tc_runtime.hip.inc"),
+    deps = [os.path.join(CSRC, "ipm_newton_eq.hip.inc" if _solver_of(spec) == "ipmPDeq_CSsolver" else "ipm_newton.hip.inc"),
+            os.path.join(CSRC, "tc_runtime.hip.inc"),
             os.path.join(CSRC, "tc_wave.hip.inc"), os.path.join(CSRC, "tc_interp.hip.inc"),
             os.path.join(CSRC, "tc_ldsm.hip.inc"), os.path.join(CSRC, "tc_pow.hip.inc"),
             os.path.join(CSRC, "tc_glibcpow.hip.inc"), os.path.join(CSRC, "tc_glibcpow_tables.inc"),

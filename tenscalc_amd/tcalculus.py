@@ -25,7 +25,7 @@ __all__ = [
     "plus", "tprod", "mtimes", "times", "rdivide", "norm2", "norminf", "norm1",
     "compose", "componentwise", "tabs", "sqr", "sqrt", "cube", "exp", "log", "sin", "cos", "inv_",
     "heaviside", "relu", "tmin", "tmax", "min2", "max2", "clp", "cat", "subsref",
-    "reshape", "repmat", "diag", "transpose", "ldl", "ldl_d", "ldl_l", "mldivide",
+    "reshape", "repmat", "diag", "transpose", "ldl", "ldl_d", "ldl_l", "lu", "mldivide", "gradientVector",
     "full", "tsum", "gradient", "hessian", "substitute", "toT", "expand",
     "ispositive", "iszero", "vec",
 ]
@@ -768,10 +768,21 @@ def ldl_l(f):
     return Tcalculus.make("ldl_l", f.size, (f,))
 
 
+def lu(A, tag=""):
+    """Symbolic LU with row and column orders fixed at code-generation time from typical values
+    (Tcalculus.m ``lu``, @csparse/sparsity_lu.m): used by the equilibrium solvers, whose Newton matrix is not
+    symmetric (lib/ipmPDeqlat_CS.m:653)."""
+    A = toT(A)
+    if A.ndim != 2 or A.size[0] != A.size[1]:
+        raise ValueError("LU decomposition only implemented for square matrices")
+    return Tcalculus.make("lu", A.size, (A,), (str(tag),))
+
+
 def mldivide(f, b):
-    """``ldl(A)\\b`` (split into l1/d/u1 solves by csparse, csparse.m:906-957)."""
+    """``ldl(A)\\b`` (split into l1/d/u1 solves by csparse, csparse.m:906-957) or ``lu(A)\\b`` (l1/u solves,
+    csparse.m:880-902)."""
     b = toT(b)
-    if f.op != "ldl":
+    if f.op not in ("ldl", "lu"):
         f = ldl(f)
     if b.ndim not in (1, 2) or b.size[0] != f.size[0]:
         raise ValueError("mldivide: size mismatch")
@@ -818,7 +829,7 @@ def _gradient(f, var):
         return Tzeros(gsize)
     if op == "variable":
         return Teye(gsize) if f is var else Tzeros(gsize)
-    gs = [gradient(a, var) for a in f.args] if op not in ("mldivide", "ldl", "ldl_d", "ldl_l") else None
+    gs = [gradient(a, var) for a in f.args] if op not in ("mldivide", "ldl", "ldl_d", "ldl_l", "lu") else None
     vix = tuple(range(1, nv + 1))
     if op == "plus":
         return plus(gs, f.par)
@@ -893,7 +904,7 @@ def _gradient(f, var):
             return tprod(e3, (1, 2, -1), gs[0], (-1,) + tuple(2 + k for k in vix))
         e3 = _eye3(n)     # matrix -> vector: d[i,v] = sum_jk eye3[j,k,i] g[j,k,v]
         return tprod(e3, (-1, -2, 1), gs[0], (-1, -2) + tuple(1 + k for k in vix))
-    if op in ("min", "max", "min2", "max2", "clp", "norminf", "norm1", "ldl", "ldl_d", "ldl_l"):
+    if op in ("min", "max", "min2", "max2", "clp", "norminf", "norm1", "ldl", "ldl_d", "ldl_l", "lu"):
         raise NotImplementedError(f"gradient of {op} not implemented (not smooth)")
     if op == "mldivide":
         F, b = f.args
@@ -921,6 +932,16 @@ def _eye3(n):
     i = np.arange(n)
     a[i, i, i] = 1.0
     return Tconstant(a)
+
+
+def gradientVector(obj, variables):
+    """lib/gradientVector.m: the gradients of a vector (or scalar) expression with respect to several vector variables,
+    side by side -- [n, sum of the variables' lengths] (empty variables are skipped)."""
+    obj = toT(obj)
+    gs = [gradient(obj, v) for v in variables if _prod(v.size) > 0]
+    if not gs:
+        return Tzeros(tuple(obj.size) + (0,))
+    return gs[0] if len(gs) == 1 else cat(obj.ndim + 1, *gs)
 
 
 def hessian(f, var, var2=None):
@@ -1012,6 +1033,8 @@ def _rebuild(f, a):
         return full(a[0])
     if op == "ldl":
         return ldl(a[0], f.par[0], f.par[1])
+    if op == "lu":
+        return lu(a[0], f.par[0])
     if op == "ldl_d":
         return ldl_d(a[0])
     if op == "ldl_l":

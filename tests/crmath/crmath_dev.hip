@@ -9,7 +9,7 @@ __global__ void crm_kernel(const double *x, double *a, double *b, double *c, dou
   const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
   if (i < n) {
     a[i] = TC_POW_NEG(x[i], -.5); b[i] = TC_POW_NEG(x[i], -1.5);
-    c[i] = tc_cr_rsqrt(x[i]); d[i] = tc_cr_rsqrt3(x[i]);
+    c[i] = tc_cr_rsqrt(x[i]); d[i] = TC_POW_HALF(x[i]);      // d: the Newton loops' pow(mu,.5)
   }
 }
 extern "C" int crm_dev_eval(const double *x, double *a, double *b, double *c, double *d, long n) {

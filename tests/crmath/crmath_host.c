@@ -9,6 +9,9 @@ void libm_eval(const double *x, double *rs, double *rs3, long n) {
   for (long i = 0; i < n; i++) { rs[i] = pow(x[i], -.5); rs3[i] = pow(x[i], -1.5); }
 }
 #include "tc_glibcpow.hip.inc"
+void half_eval(const double *x, double *emul, double *libm, long n) {
+  for (long i = 0; i < n; i++) { emul[i] = tc_glibc_pow_frac(x[i], .5); libm[i] = pow(x[i], .5); }
+}
 void glibc_emul_eval(const double *x, double *rs, double *rs3, long n) {
   for (long i = 0; i < n; i++) { rs[i] = tc_glibc_pow_negfrac(x[i], -.5); rs3[i] = tc_glibc_pow_negfrac(x[i], -1.5); }
 }

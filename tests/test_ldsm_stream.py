@@ -162,10 +162,14 @@ class Machine:
         self.clean -= set(e["children"])
 
 
-def _check(spec, data, tape_oracle, args, W=1, lds_slots=20000, stream_kw=None):
+def _check(spec, data, tape_oracle, args, W=1, lds_slots=20000, stream_kw=None, fuse=False):
     T, c, D = spec.tape, spec.classname, spec.defines
+    o = tape_oracle(T, c)                    # the oracle always walks the reference's partition into groups
+    if fuse:                                 # ... the machine the coarser one of hip_emitter.emit_class_ldsm(fuse_chain=True)
+        fs = lsch.fusion_sets(T, min_gain=32 if fuse is True else int(fuse))
+        assert fs, "nothing to fuse on this tape"
+        T = T.merged(fs)
     cs = lsch.class_stream(T, c, D, W=W, lds_slots=lds_slots, **(stream_kw or {}))
-    o = tape_oracle(T, c)
     mach = Machine(T, cs)
 
     def both(kind, name, *a):
@@ -238,6 +242,32 @@ def test_ldsm_stream_dcmotor(native_built, tape_oracle, tmp_path, W):
     from tenscalc_amd.problems.mpc_dcmotor import SOLVE_ARGS, dcmotor_data, mpc_dcmotor
     spec = mpc_dcmotor(folder=str(tmp_path))
     _check(spec, dcmotor_data(7), tape_oracle, SOLVE_ARGS, W)
+
+
+@pytest.mark.parametrize("W", [1, 4])
+def test_ldsm_stream_dcmotor_fused_factor_and_solves(native_built, tape_oracle, tmp_path, W):
+    """the KKT factorisation and the triangular solves walked as ONE level schedule (csparse.Tape.merged +
+    ldsm_schedule.fusion_sets): coarser dependency groups, fewer barrier-separated steps, the same values"""
+    from tenscalc_amd.problems.mpc_dcmotor import SOLVE_ARGS, dcmotor_data, mpc_dcmotor
+    spec = mpc_dcmotor(folder=str(tmp_path))
+    T = spec.tape
+    fs = lsch.fusion_sets(T)
+    T2 = T.merged(fs)
+    assert T2.nGroups == T.nGroups - sum(len(s_) - 1 for s_ in fs)
+    assert sum(lsch.stream_levels(T2)[1]) <= sum(lsch.stream_levels(T)[1]) - 32 * len(fs)
+    with pytest.raises(ValueError, match="cycle"):
+        a, b_ = fs[0][0], fs[0][-1]
+        if len(fs[0]) > 2:
+            T.merged([[a, b_]])
+        else:
+            raise ValueError("cycle: (no group lies between these two)")
+    _check(spec, dcmotor_data(7), tape_oracle, SOLVE_ARGS, W, fuse=True)
+
+
+def test_ldsm_stream_small_quadcopter_fused(native_built, tape_oracle, tmp_path):
+    from tenscalc_amd.problems.mpc_quadcopter import SOLVE_ARGS, mpc_quadcopter, quadcopter_data
+    spec = mpc_quadcopter(T=8, classname="tmp_quadcopter8", folder=str(tmp_path))
+    _check(spec, quadcopter_data(1, T=8), tape_oracle, SOLVE_ARGS, W=4, fuse=4)      # short horizon: small gains count
 
 
 def test_ldsm_stream_dcmotor_small_lds(native_built, tape_oracle, tmp_path):
