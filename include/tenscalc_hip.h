@@ -96,6 +96,9 @@ int tc_get_device(tc_solver_t *h, const double **outputs, const int32_t **status
                   const int32_t **iter);
 int64_t tc_output_offset(int k);          /* row of output k inside the SoA outputs block */
 int tc_synchronize(tc_solver_t *h);
+/* the handle's own stream (a hipStream_t as void*): a caller that enqueues its work THERE -- e.g. records its timing
+ * events on it and passes it to tc_solve_async -- needs no cross-stream event per call */
+int tc_get_stream(tc_solver_t *h, void **stream);
 
 /* ---- diagnostics: evaluate one tape `get` entry point (getGrad__, getJ__, ...) right after
  * the solver's initialisation sequence (initPrimal__, scaleIneq__, setMu__(mu0),

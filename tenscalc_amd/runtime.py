@@ -72,6 +72,7 @@ def _bind(path):
     L.tc_get_device.argtypes = [c.c_void_p, c.POINTER(c.c_void_p), c.POINTER(c.c_void_p),
                                 c.POINTER(c.c_void_p)]
     L.tc_synchronize.argtypes = [c.c_void_p]
+    L.tc_get_stream.argtypes = [c.c_void_p, c.POINTER(c.c_void_p)]
     L.tc_probe.argtypes = [c.c_void_p, c.c_char_p, c.c_double, _dp, _dp, c.c_int64]
     L.tc_stats_rows.restype = c.c_int64
     L.tc_get_stats.argtypes = [c.c_void_p, _dp]
@@ -186,6 +187,12 @@ class HipSolver:
         ae = np.array(addEye2Hessian, dtype=np.float64).reshape(2)
         self._check(self._L.tc_solve_async(self._h, float(mu0), int(maxIter), ae.ctypes.data_as(_dp),
                                            ctypes.c_void_p(stream or 0)))
+
+    def stream(self):
+        """the handle's own stream (hipStream_t as an int): wrap it with torch.cuda.ExternalStream to enqueue there"""
+        p = ctypes.c_void_p(0)
+        self._check(self._L.tc_get_stream(self._h, ctypes.byref(p)))
+        return int(p.value or 0)
 
     def synchronize(self):
         self._check(self._L.tc_synchronize(self._h))

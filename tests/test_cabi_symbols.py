@@ -39,7 +39,8 @@ def test_reference_symbols_exported(libs):
         inputs = [L.tc_input_name(k).decode() for k in range(L.tc_num_inputs())]
         assert len(inputs) >= 3
         # writeCfunctionpergroup.m:524,607-635; ipmPD_CSsolver.c:132 (unprefixed name)
-        for n in [f"{cls}_set_{i}" for i in inputs] + [f"{cls}_getOutputs", "ipmPD_CSsolver"]:
+        solver = "ipmPDeq_CSsolver" if tag.startswith("games_") else "ipmPD_CSsolver"     # ipmPDeq_CSsolver.c:122 for equilibrium classes
+        for n in [f"{cls}_set_{i}" for i in inputs] + [f"{cls}_getOutputs", solver]:
             assert hasattr(L, n), f"{tag}: {n} missing"
 
 
