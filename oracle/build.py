@@ -28,8 +28,13 @@ def _run(cmd):
 def build_oracle(opt="-O1"):
     """-O1 is the reference's "fastest run-time" setting (examples/l1l2estimationCS.m:22-25).
     -ffp-contract=off: the reference build targets plain x86-64 (no FMA)."""
-    out = os.path.join(HERE, "libtc_oracle.so")
+    san = os.environ.get("TC_SANITIZE")      # scripts/sanitize_cpu.sh: AddressSanitizer + UBSan build of the checker
+    out = os.path.join(HERE, "libtc_oracle_san.so" if san else "libtc_oracle.so")
     srcs = [os.path.join(HERE, "tc_oracle.c"), os.path.join(HERE, "tc_oracle_eq.c")]
+    if san:
+        _run(["gcc", "-O1", "-g", "-fsanitize=address,undefined", "-fno-omit-frame-pointer", "-ffp-contract=off", "-std=gnu99",
+              "-fPIC", "-shared", "-I", HERE] + srcs + ["-o", out, "-lm"])
+        return out
     if os.path.exists(out) and os.path.getmtime(out) >= max(
             [os.path.getmtime(s_) for s_ in srcs] + [os.path.getmtime(os.path.join(HERE, "tc_oracle.h"))]):
         return out

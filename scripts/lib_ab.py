@@ -14,20 +14,29 @@ MODS = {"dcmotor": ("tenscalc_amd.problems.mpc_dcmotor", "mpc_dcmotor", "dcmotor
         "l1l2": ("tenscalc_amd.problems.l1l2", "l1l2", "l1l2_data"),
         "quadcopter": ("tenscalc_amd.problems.mpc_quadcopter", "mpc_quadcopter", "quadcopter_data")}
 which, B, tags = sys.argv[1], int(sys.argv[2]), sys.argv[3:]
-mod = importlib.import_module(MODS[which][0])
-spec = getattr(mod, MODS[which][1])(folder=g.GENERATED)
-data = getattr(mod, MODS[which][2])
+if which == "sls":
+    mod = importlib.import_module("tenscalc_amd.problems.sls")
+    spec = g.sls_spec("w8x")
+    A_, b_, x_ = mod.sls_batch(min(B, 4096))
+    rep = -(-B // A_.shape[0])
+    host = {"A": np.tile(np.ascontiguousarray(np.transpose(A_, (0, 2, 1))).reshape(A_.shape[0], -1), (rep, 1))[:B],
+            "b": np.tile(b_, (rep, 1))[:B], "x": np.tile(x_, (rep, 1))[:B]}
+else:
+    mod = importlib.import_module(MODS[which][0])
+    spec = getattr(mod, MODS[which][1])(folder=g.GENERATED)
+    data = getattr(mod, MODS[which][2])
+    ds = [data(k) for k in range(B)]
+    host = {n: np.stack([np.asarray(x[n], dtype=float).reshape(-1, order="F") for x in ds])
+            for n in [n for n, _ in spec.parameters + spec.variables]}
 d = os.path.join(g.GENERATED, "@" + spec.classname)
 names = [n for n, _ in spec.parameters + spec.variables]
-ds = [data(k) for k in range(B)]
-host = {n: np.stack([np.asarray(x[n], dtype=float).reshape(-1, order="F") for x in ds]) for n in names}
 ref = None
 for tag in tags:
     obj = HipSolver(os.path.join(d, "lib%s_%s.so" % (spec.classname, tag)), B=B)
     for n in names:
         obj.set(n, host[n])
     ts = []
-    for _ in range(5):
+    for _ in range(9):
         st, it, tm = obj.solve(**mod.SOLVE_ARGS)
         ts.append(tm)
     out = np.concatenate([o.reshape(B, -1) for o in obj.getOutputs()], axis=1)

@@ -114,7 +114,8 @@ _LIB = None
 def _lib():
     global _LIB
     if _LIB is None:
-        path = os.path.join(_HERE, "libtcitable.so")
+        # TC_SANITIZE: the AddressSanitizer / UBSan build of the table (scripts/sanitize_cpu.sh)
+        path = os.path.join(_HERE, "libtcitable_san.so" if os.environ.get("TC_SANITIZE") else "libtcitable.so")
         if not os.path.exists(path):
             raise RuntimeError(
                 f"{path} missing: run `python -c 'import __graft_entry__ as g; g.build()'`")
