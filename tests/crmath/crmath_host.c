@@ -9,8 +9,21 @@ void libm_eval(const double *x, double *rs, double *rs3, long n) {
   for (long i = 0; i < n; i++) { rs[i] = pow(x[i], -.5); rs3[i] = pow(x[i], -1.5); }
 }
 #include "tc_glibcpow.hip.inc"
+/* fraction of arguments that take the shortcut (the hardware's sqrt) in tc_glibc_pow_half */
+long half_shortcuts(const double *x, long n) {
+  long k = 0;
+  for (long i = 0; i < n; i++) {
+    const double v = x[i];
+    if (v >= 0x1p-1000 && v < 0x1p1000) {
+      const double s = sqrt(v), e = fma(-s, s, v);
+      const double u = tcg_f64((tcg_u64(s) & 0x7ff0000000000000ULL) - (52ULL << 52));
+      k += fabs(e) <= 0.875 * s * u;
+    }
+  }
+  return k;
+}
 void half_eval(const double *x, double *emul, double *libm, long n) {
-  for (long i = 0; i < n; i++) { emul[i] = tc_glibc_pow_frac(x[i], .5); libm[i] = pow(x[i], .5); }
+  for (long i = 0; i < n; i++) { emul[i] = tc_glibc_pow_half(x[i]); libm[i] = pow(x[i], .5); }
 }
 void glibc_emul_eval(const double *x, double *rs, double *rs3, long n) {
   for (long i = 0; i < n; i++) { rs[i] = tc_glibc_pow_negfrac(x[i], -.5); rs3[i] = tc_glibc_pow_negfrac(x[i], -1.5); }

@@ -133,8 +133,13 @@ def test_host_build_of_the_glibc_restatement_is_the_hosts_pow():
     assert np.array_equal(a, pa, equal_nan=True)
     assert np.array_equal(b, pb, equal_nan=True)
     # pow(mu,.5) of the Newton loops (ipmPD_CSsolver.c:801): NOT sqrt(mu) -- glibc differs from it on 8e-4 of arguments
+    # (tc_glibc_pow_half: the hardware's sqrt unless x is within 1/16 ulp of a rounding boundary of sqrt, where glibc's
+    # 0.52-ulp result may differ; else the restated algorithm)
     e, l = _eval(L.half_eval, x)
     assert np.array_equal(e, l, equal_nan=True)
+    L.half_shortcuts.restype = ctypes.c_long
+    k = L.half_shortcuts(np.ascontiguousarray(x).ctypes.data_as(ctypes.POINTER(ctypes.c_double)), ctypes.c_long(x.size))
+    assert .8 < k / x.size < .9                     # 7/8 of the arguments take the shortcut
     with np.errstate(invalid="ignore"):
         assert 1e-4 < np.mean(l[x > 0] != np.sqrt(x[x > 0])) < 5e-3
 
