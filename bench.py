@@ -383,7 +383,7 @@ def bench_sls(args, R):
         total = args.total or B * world
         out = {
             "metric": "IPM solves/sec (whole node), sls N=100 n=8 batch",
-            "value": value, "unit": "solves/s", "n_gpus": len(R.devices), "steps": args.steps, "warmup": args.warmup,
+            "value": value, "unit": "solves/s", "n_gpus": len(set(R.devices)), "ranks": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True,
             "scaling": "strong" if args.total else "weak",
             "vs_baseline": None, "dtype": "f64", "data": "synthetic",
@@ -696,7 +696,7 @@ def bench_config(args, R):
         achieved = algo * B / kavg / 1e9
         total = args.total or B * world
         out = {"metric": "IPM solves/sec (whole node), %s batch" % args.config, "value": ok * args.steps / elapsed,
-               "unit": "solves/s", "n_gpus": len(R.devices), "steps": args.steps, "warmup": args.warmup,
+               "unit": "solves/s", "n_gpus": len(set(R.devices)), "ranks": world, "steps": args.steps, "warmup": args.warmup,
                "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True,
                "scaling": "strong" if args.total else "weak", "vs_baseline": None,
                "dtype": "f64", "data": "synthetic",

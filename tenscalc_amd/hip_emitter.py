@@ -62,7 +62,9 @@ def _lit(v):
 def _solver_of(spec):
     """name of the Newton-loop template the class pastes behind its tape: ipmPD_CSsolver (cmex2optimizeCS.m:95,286) or
     ipmPDeq_CSsolver (cmex2equilibriumLatentCS.m:401,451)"""
-    return getattr(spec, "solver", "ipmPD_CSsolver")
+    # (classes rebuilt from tape / .cg files carry no attribute: the equilibrium solvers' #define block has nZ,
+    # cmex2equilibriumLatentCS.m:418, the optimisation solvers' has not)
+    return getattr(spec, "solver", None) or ("ipmPDeq_CSsolver" if "nZ" in spec.defines else "ipmPD_CSsolver")
 
 
 def _define_block(spec):
