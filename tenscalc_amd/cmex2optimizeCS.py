@@ -168,8 +168,6 @@ def cmex2optimizeCS(*, classname, objective, optimizationVariables, constraints=
             raise NotImplementedError("smallerNewtonMatrix=true needs lambdaUpdate='additive' (ipmPD_CStimesLambda.m:34-36)")
     if not useLDL or useUmfpack:
         raise NotImplementedError("only the LDL path is implemented (ipmPD_CStimesLambda.m:40-45)")
-    if allowSave:
-        raise NotImplementedError("allowSave is not supported by the HIP back-end")
     classname = re.sub(r"[-+]", "_", classname)
     objective = tc.toT(objective)
     if objective.size != ():
@@ -238,6 +236,9 @@ def cmex2optimizeCS(*, classname, objective, optimizationVariables, constraints=
         outputExpressions = [rewrite(o) for o in outputExpressions]
     outputExpressions = [tc.full(o) for o in outputExpressions]
     code.declareGet(outputExpressions, f"{classname}_getOutputs", list(outputNames))
+    if allowSave:        # ipmPD_CStimesLambda.m:283-291: declareSave(code,WW,'saveWW__',<cls>_WW.subscripts).  Here a get
+        # of the Newton matrix that HipSolver.saveWW evaluates after the initialisation sequence (tenscalc_amd/typical.py)
+        code.declareGet([tc.full(Tout["Hess"])], "saveWW__", ["WW"])
 
     # the reference passes the real-valued options to the C template through sprintf('%e') (cmex2optimizeCS.m:303-331):
     # six significant digits.  The same rounding here, so that a non-default value such as muFactorAggressive=1/3
@@ -259,6 +260,14 @@ def cmex2optimizeCS(*, classname, objective, optimizationVariables, constraints=
         delta=int(delta), skipAffine=int(bool(skipAffine) or nF == 0), smallerNewtonMatrix=int(bool(smallerNewtonMatrix)), useLDL=1, useUmfpack=0, allowSave=0,
         debugConvergence=0, profiling=0, verboseLevel=int(solverVerboseLevel))
     tape = code.compile(defines)
+    if allowSave:
+        import os
+        from . import typical
+        classdir = os.path.join(folder, "@" + classname)
+        os.makedirs(classdir, exist_ok=True)
+        wsubs, _ = code.scalarize(Tout["Hess"])
+        typical.write_subscripts(os.path.join(classdir, classname + "_WW.subscripts"), Tout["Hess"].size, wsubs,
+                                 typical.new_magic())
     spec = SolverSpec(classname, tape, defines,
                       [(p.par, p.size) for p in parameters],
                       [(v.par, v.size) for v in optimizationVariables],

@@ -19,6 +19,8 @@ all consume.
 """
 from __future__ import annotations
 
+import os
+
 import numpy as np
 
 from . import instructions as I
@@ -885,6 +887,27 @@ class CSparse:
         return (np.vstack([subs[k], np.stack([d, d], 1)]),
                 np.concatenate([ins[k], np.full(N, one, dtype=np.int64)]))
 
+    def _typical(self, tag, size, subs):
+        """values of the matrix `tag` saved by an earlier run (<typical_folder>/<tag>.subscripts/.values, tenscalc_amd/typical.py)
+        in the order of `subs`, or None (no files, another sparsity structure, mismatching magic numbers:
+        sparsity_lu.m:38-41 then falls back to random values)"""
+        folder = getattr(self, "typical_folder", None)
+        if not folder or not tag:
+            return None
+        from . import typical
+        r = typical.load(os.path.join(folder, tag + ".subscripts"), os.path.join(folder, tag + ".values"))
+        if r is None:
+            return None
+        osize, tsubs, tvals = r
+        if tuple(osize) != tuple(size) or tsubs.shape != subs.shape:
+            return None
+        key = {tuple(x): k for k, x in enumerate(tsubs.tolist())}
+        try:
+            idx = [key[tuple(x)] for x in subs.tolist()]
+        except KeyError:
+            return None
+        return tvals[idx]
+
     # ---- LU with row / column orders fixed at code-generation time (@csparse/sparsity_lu.m) ----------
     def _s_lu(self, n):
         """Right-looking symbolic Gaussian elimination of A(p,q).  p, q come from a NUMERICAL sparse LU of the matrix
@@ -904,6 +927,15 @@ class CSparse:
             raise ValueError("lu: empty matrix")
         uniq, inv = np.unique(ins, return_inverse=True)
         vals = (1 + .5 * np.random.RandomState(0).random_sample(len(uniq)))[inv]
+        typ = self._typical(n.par[0], n.size, subs)
+        how = "random values"
+        if typ is not None:                      # sparsity_lu.m:51-57: the saved matrix + noise that removes exact zeros
+            if np.isnan(typ).any():
+                raise ValueError("typical values include %d nan entries" % int(np.isnan(typ).sum()))
+            nz = np.abs(typ[typ != 0])
+            tol = (nz.min() if nz.size else 1.0) * np.finfo(float).eps ** 2
+            vals = typ + tol * np.random.RandomState(0).standard_normal(typ.size)
+            how = "typical values"
         Atyp = sp.csc_matrix((vals, (subs[:, 0], subs[:, 1])), shape=(N, N))
         f = splu(Atyp, permc_spec="COLAMD", diag_pivot_thresh=0.01)
         p = np.argsort(f.perm_r)              # A[p][:, q] = L U
@@ -955,7 +987,7 @@ class CSparse:
                 S.append((k, c))
                 Ins.append(i)
         self.lu_perm[n.idx] = (p[pp], q)
-        self.lu_stats.append(dict(n=N, nnzA=len(ins), nnzLU=len(Ins), new_instructions=len(t) - n0, tag=n.par[0],
+        self.lu_stats.append(dict(n=N, nnzA=len(ins), nnzLU=len(Ins), new_instructions=len(t) - n0, tag=n.par[0], order_from=how,
                                   changed_pivots=int((pp != np.arange(N)).sum())))
         return _sort_cm(np.array(S, dtype=np.int64).reshape(-1, 2), np.array(Ins, dtype=np.int64), n.size)
 

@@ -310,7 +310,7 @@ def ipmPDeqlat_CS(code, *, u, d, x, f, g, Fu, Fd, Gu, Gd, H, P1lambda, P1nu, P1x
     if nFd > 0:
         dst.append(P2lambda); src.append(newLambda_s[nFu:nF])
     code.declareCopy(dst, src, "updatePrimalDual__")
-    out.update(u=u, d=d, x=x, F=F, G=G, nu=nu, dx_s=dx_s, b_s=b_s)
+    out.update(u=u, d=d, x=x, F=F, G=G, nu=nu, dx_s=dx_s, b_s=b_s, WW=WWraw)
     out["lambda"] = lam
     return out
 
@@ -364,8 +364,6 @@ def cmex2equilibriumLatentCS(*, classname, P1objective, P2objective, P1optimizat
             raise TypeError("cmex2equilibriumLatentCS: unknown option(s) %s" % ", ".join(bad))
     if useUmfpack:
         raise NotImplementedError("useUmfpack is not supported by the HIP back-end")
-    if allowSave:
-        raise NotImplementedError("allowSave is not supported by the HIP back-end")
     classname = re.sub(r"[-+]", "_", classname)
     P1objective, P2objective = tc.toT(P1objective), tc.toT(P2objective)
     if P1objective.size != ():
@@ -386,6 +384,9 @@ def cmex2equilibriumLatentCS(*, classname, P1objective, P2objective, P1optimizat
         outputNames = [o.par if o.op == "variable" else f"y{k + 1}" for k, o in enumerate(outputExpressions)]
 
     code = CSparse()
+    import os
+    classdir = os.path.join(folder, "@" + classname)
+    code.typical_folder = classdir     # <cls>_WW.subscripts/.values of an earlier run order the LU (sparsity_lu.m:36-57)
     for p in parameters:
         code.declareSet(p, f"{classname}_set_{p.par}", external=True)
     for v in P1v + P2v + Lv:
@@ -434,6 +435,8 @@ def cmex2equilibriumLatentCS(*, classname, P1objective, P2objective, P1optimizat
         outputExpressions = [substitute(o, ph, val) for o in outputExpressions]
     outputExpressions = [full(o) for o in outputExpressions]
     code.declareGet(outputExpressions, f"{classname}_getOutputs", list(outputNames))
+    if allowSave:        # ipmPDeqlat_CS.m:838-850: declareSave(code,WW,'saveWW__',<cls>_WW.subscripts)
+        code.declareGet([full(Tout["WW"])], "saveWW__", ["WW"])
 
     pe = lambda v: float("%e" % float(v))          # noqa: E731  (sprintf('%e'), cmex2equilibriumLatentCS.m:425-438)
     nU, nD, nX = _n(u), _n(d), _n(x)
@@ -448,9 +451,15 @@ def cmex2equilibriumLatentCS(*, classname, P1objective, P2objective, P1optimizat
         coupledAlphas=int(bool(coupledAlphas)), setAddEye2Hessian=int(bool(addEye2Hessian)),
         adjustAddEye2Hessian=int(bool(adjustAddEye2Hessian)), muFactorAggressive=pe(muFactorAggressive),
         muFactorConservative=pe(muFactorConservative), delta=int(delta), skipAffine=int(bool(skipAffine) or nF == 0),
-        smallerNewtonMatrix=int(bool(smallerNewtonMatrix)), useLDL=int(bool(useLDL)), useUmfpack=0, allowSave=0,
+        smallerNewtonMatrix=int(bool(smallerNewtonMatrix)), useLDL=int(bool(useLDL)), useUmfpack=0, allowSave=0,      # (the LOOP never saves: HipSolver.saveWW does)
         debugConvergence=0, debugConvergenceThreshold=1e5, profiling=0, verboseLevel=int(solverVerboseLevel))
     tape = code.compile(defines)
+    if allowSave:        # after compile: the LU above has used the pair an EARLIER run left (ipmPDeqlat_CS.m:836-837)
+        from . import typical
+        os.makedirs(classdir, exist_ok=True)
+        wsubs, _ = code.scalarize(Tout["WW"])
+        typical.write_subscripts(os.path.join(classdir, classname + "_WW.subscripts"), Tout["WW"].size, wsubs,
+                                 typical.new_magic())
     spec = SolverSpec(classname, tape, defines, [(p.par, p.size) for p in parameters],
                       [(v.par, v.size) for v in P1v + P2v + Lv],
                       [(nm, o.size) for nm, o in zip(outputNames, outputExpressions)], folder)

@@ -238,6 +238,25 @@ class HipSolver:
         return out
 
 
+    def saveWW(self, filename=None, instance=0, mu0=1.0, addEye2Hessian=(1e-9, 1e-9)):
+        """``saveWW__`` of classes generated with allowSave=True: the values of the Newton matrix of `instance`, evaluated
+        right after the initialisation sequence (the first iteration's WW; the reference writes the one of iteration
+        saveIter, ipmPD_CSsolver.c:561-566), written as ``<cls>_WW.values`` next to the ``<cls>_WW.subscripts`` file the code
+        generator left beside the library (tenscalc_amd/typical.py).  A later code generation in the same folder picks
+        the pair up and orders the symbolic LU with these values instead of random ones (sparsity_lu.m:36-57)."""
+        import os
+        from . import typical
+        base = os.path.join(os.path.dirname(os.path.abspath(self.library)), self.classname + "_WW")
+        if not os.path.exists(base + ".subscripts"):
+            raise TensCalcHipError("saveWW: %s.subscripts not found (generate the class with allowSave=True)" % base)
+        magic, osize, subs = typical.read_subscripts(base + ".subscripts")
+        nd = len(osize)
+        dense = self.probe("saveWW__", mu0=mu0, addEye2Hessian=addEye2Hessian)[int(instance)]
+        dense = dense.reshape(osize, order="F")
+        vals = dense[tuple(subs[:, k] for k in range(nd))]
+        return typical.write_values(filename or (base + ".values"), vals, magic)
+
+
 def load_class(spec, B=1, device=0, **build_kw):
     """``obj=feval(classname)``: build (if needed) and instantiate."""
     so = spec.build(**build_kw)

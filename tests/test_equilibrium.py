@@ -177,6 +177,46 @@ def test_quadratic_saddle_point_closed_form(native_built, tmp_path, name):
         assert abs(out[2 * N] - N * 10 / 9) <= 1e-3
 
 
+def test_typical_values_files_order_the_lu(native_built, tmp_path, tape_oracle):
+    """allowSave workflow (sparsity_lu.m:36-57, writeCfunctionpergroup.m:879-918): generation 1 writes <cls>_WW.subscripts and
+    orders the LU with random values; a saved <cls>_WW.values (here produced through the oracle's saveWW__ get; on the GPU
+    by HipSolver.saveWW) makes generation 2 order it with the typical matrix; the solution does not change beyond
+    rounding; a pair with mismatching magic numbers is ignored (loadCSparse.m)."""
+    from tenscalc_amd import typical
+    from tenscalc_amd.problems import tc_games as tg
+    kw = dict(N1=7, N2=5, classname="tmp_ms_save", folder=str(tmp_path), allowSave=True)
+    spec = tg.matrixsaddle(**kw)
+    base = str(tmp_path / "@tmp_ms_save" / "tmp_ms_save_WW")
+    assert spec.code.lu_stats[-1]["order_from"] == "random values" and spec.tape.has("saveWW__")
+    magic, osize, subs = typical.read_subscripts(base + ".subscripts")
+    n = 7 + 5 + 2 + 12
+    assert osize == (n, n) and subs.min() >= 0 and subs.max() < n
+    d = tg.matrixsaddle_data(3, 7, 5)
+    o = tape_oracle(spec.tape, "save")
+    c = spec.classname
+    for nm, _ in spec.parameters + spec.variables:
+        o.set(f"{c}_set_{nm}", d[nm])
+    for e in ("initPrimal__", "scaleIneq__"):
+        o.copy(e)
+    o.set("setMu__", [1.0])
+    o.copy("initDualIneq__")
+    o.copy("initDualEq__")
+    W = o.get("saveWW__").reshape(osize, order="F")
+    assert np.count_nonzero(W) <= len(subs) and np.count_nonzero(W[subs[:, 0], subs[:, 1]]) == np.count_nonzero(W)
+    typical.write_values(base + ".values", W[subs[:, 0], subs[:, 1]], magic)
+    r = typical.load(base + ".subscripts", base + ".values")
+    assert r is not None and r[0] == osize and np.array_equal(r[1], subs)
+    st1, it1, y1 = _solve(o, spec, d, tg.SOLVE_ARGS)
+    spec2 = tg.matrixsaddle(**kw)                               # generation 2: reads the pair, then writes new subscripts
+    assert spec2.code.lu_stats[-1]["order_from"] == "typical values"
+    o2 = tape_oracle(spec2.tape, "save2")
+    st2, it2, y2 = _solve(o2, spec2, d, tg.SOLVE_ARGS)
+    assert st1 == st2 == 0 and abs(it1 - it2) <= 1 and np.abs(y1 - y2).max() <= 1e-6
+    assert typical.load(base + ".subscripts", base + ".values") is None           # new magic: the old values no longer match
+    spec3 = tg.matrixsaddle(**kw)
+    assert spec3.code.lu_stats[-1]["order_from"] == "random values"
+
+
 def test_front_door_argument_checks(native_built):
     from tenscalc_amd import tcalculus as tc
     from tenscalc_amd.equilibrium import cmex2equilibriumLatentCS
@@ -234,3 +274,41 @@ def test_gpu_equilibrium_classes_bit_exact(tmp_path, name, variant):
         assert np.array_equal(got, ref, equal_nan=True)
         if maxIter > 4:
             assert (st == 0).sum() >= B - 3 and st[7] == 4
+
+
+@pytest.mark.gpu
+def test_gpu_saveWW_writes_the_reference_file_pair(tmp_path):
+    """HipSolver.saveWW: the Newton matrix of one instance after the initialisation sequence, in the reference's
+    .subscripts / .values format, equal to the oracle's saveWW__ at the same point"""
+    import __graft_entry__ as g
+    from tenscalc_amd import typical
+    from tenscalc_amd.problems import tc_games as tg
+    from tenscalc_amd.runtime import HipSolver
+    from tenscalc_amd.tapeio import save_tape
+    from oracle.tc_oracle import Oracle
+    spec = tg.matrixsaddle(N1=7, N2=5, classname="tmp_ms_save", folder=str(tmp_path), allowSave=True)
+    so = spec.build(**g.VARIANT_KW["strict"])
+    B = 5
+    data = [tg.matrixsaddle_data(40 + k, 7, 5) for k in range(B)]
+    obj = HipSolver(so, B=B, device=0)
+    for n, _ in spec.parameters + spec.variables:
+        obj.set(n, np.stack([np.asarray(d[n], dtype=float).reshape(-1, order="F") for d in data]))
+    path = obj.saveWW(instance=3)
+    obj.close()
+    base = path[:-len(".values")]
+    osize, subs, vals = typical.load(base + ".subscripts", path)
+    tape = str(tmp_path / "s.tape")
+    save_tape(spec.tape, tape)
+    o = Oracle(tape)
+    c = spec.classname
+    for n, _ in spec.parameters + spec.variables:
+        o.set(f"{c}_set_{n}", data[3][n])
+    for e in ("initPrimal__", "scaleIneq__"):
+        o.copy(e)
+    o.set("setMu__", [1.0])
+    o.copy("initDualIneq__")
+    o.copy("initDualEq__")
+    W = o.get("saveWW__").reshape(osize, order="F")
+    assert np.array_equal(vals, W[subs[:, 0], subs[:, 1]])
+    spec2 = tg.matrixsaddle(N1=7, N2=5, classname="tmp_ms_save", folder=str(tmp_path), allowSave=True)
+    assert spec2.code.lu_stats[-1]["order_from"] == "typical values"

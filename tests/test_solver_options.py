@@ -67,3 +67,17 @@ def test_loop_branches_bitwise_vs_reference(native_built, tmp_path, kind, opt):
         assert np.array_equal(r[0][2], r[1][2], equal_nan=True)
         nconv += r[0][0] == 0
     assert nconv >= 4
+
+
+def test_allow_save_declares_saveWW_and_writes_the_subscripts_file(native_built, tmp_path):
+    """cmex2optimizeCS(allowSave=true): the Newton matrix becomes reachable through saveWW__ and its sparsity structure is
+    written in the reference's format next to the class (ipmPD_CStimesLambda.m:283-291, writeCfunctionpergroup.m:905-916)"""
+    from tenscalc_amd import typical
+    from tenscalc_amd.problems.sls import sls
+    spec = sls(N=20, n=4, classname="tmp_sls_save", folder=str(tmp_path), allowSave=True)
+    assert spec.tape.has("saveWW__")
+    magic, osize, subs = typical.read_subscripts(str(tmp_path / "@tmp_sls_save" / "tmp_sls_save_WW.subscripts"))
+    n = 4 + 8                                   # nU + nF
+    assert osize == (n, n) and len(subs) == spec.tape.ldl_stats[-1]["nnzA"] and magic > 0
+    plain = sls(N=20, n=4, classname="tmp_sls_nosave", folder=str(tmp_path))
+    assert not plain.tape.has("saveWW__")
