@@ -584,7 +584,7 @@ CONFIGS = {
     "dcmotor": ("tenscalc_amd.problems.mpc_dcmotor", "mpc_dcmotor", "dcmotor_data", 32768, "strict", 32768,
                 "mpc_dcmotor T=30 (323x323 KKT), batch=%d parameter sweep per GPU, fp64 (BASELINE.json configs[3]: the "
                 "whole 8-GPU sweep of 32768 on one GPU by default)"),
-    "quadcopter": ("tenscalc_amd.problems.mpc_quadcopter", "mpc_quadcopter", "quadcopter_data", 512, "ldsm8", 512,
+    "quadcopter": ("tenscalc_amd.problems.mpc_quadcopter", "mpc_quadcopter", "quadcopter_data", 512, "ldsc4", 512,
                    "mpc_quadcopter T=100 (1406x1406 KKT, 67 k instructions), batch=%d per GPU, fp64 (BASELINE.json "
                    "configs[4]: the per-GPU share of 4096 over 8 GPUs)"),
 }

@@ -1519,7 +1519,76 @@ def emit_class(spec, fp_contract="fast", block=64, stats=False, roll=True, min_w
     return "".join(w), L
 
 
-def emit_class_ldsm(spec, waves=4, stats=False, lds_slots=20000, fuse_chain=True):
+def _ldsc_functions(cs, W, chunk=96, depth=8):
+    """body="ldsm", compiled=True: the record stream printed as code.  Per record range (a dependency group or a copy
+    entry point) and per wavefront of the workgroup: its records in stream order, each one a TCC_EXEC with the header
+    fields as literals (csrc/tc_ldsm.hip.inc: tcl_exec_t folds to the record's own code), its body words requested
+    `depth` records ahead into one of `depth` register sets, barriers where the stream has them; cut into functions of
+    `chunk` records (clang's time is superlinear in the size of a function).  tc_ldsm_run becomes a switch.
+    mpc_quadcopter, 512 instances, ms per batch: interpreted walk (ldsm8) 531; compiled, 1 / 2 / 4 / 8 wavefronts per
+    instance at depth 4: 566 / 369 / 294 / 278; 4 wavefronts at depth 2 / 4 / 8 / 12 / 16: 323 / 294 / 276 / 275 / 277."""
+    # functions stay at `chunk` = 96 records: a build with 384 per function (mpc_quadcopter, W = 4) took a GPU memory
+    # access fault on its first launch -- 20 k instructions per function, i.e. branch distances beyond the 16-bit
+    # offsets; never investigated further, never run again
+    depth = int(os.environ.get("TC_LDSC_DEPTH", depth))          # tuning aid (hashed into the build key)
+    hd = np.asarray(cs["headers"], dtype=np.int64).reshape(-1, 8)
+    table = cs["table"]
+    nrid = len(table) // (2 * W)
+    w = []
+    calls = {}
+    for rid in range(nrid):
+        for k in range(W):
+            h0, h1 = int(table[(rid * W + k) * 2]), int(table[(rid * W + k) * 2 + 1])
+            recs = list(range(h0, h1))
+            names = []
+            for c0 in range(0, len(recs), chunk):
+                part = recs[c0:c0 + chunk]
+                nm = f"tcc_r{rid}_w{k}_{c0 // chunk}"
+                names.append(nm)
+                body = [f"static __device__ __noinline__ void {nm}(tc_lds lds, tc_gmem gm, const int lane) {{\n"
+                        "  tc_gcode_p code = (tc_gcode_p)tc_code;\n"
+                        "  int " + ", ".join(f"R{q}[TCL_NR]" for q in range(depth)) + ";\n"]
+                real = [h for h in part if (int(hd[h, 0]) >> 8) != 2]        # records with a body (not barriers)
+
+                def lit(h):
+                    r = hd[h]
+                    return f"{int(r[0])}, {int(r[1])}, {int(r[2])}, {int(r[3])}, {int(r[4])}, {int(r[5]) | (int(r[6]) << 8)}"
+                pos = {h: q for q, h in enumerate(real)}
+                for q in range(min(depth, len(real))):
+                    body.append(f"  TCC_LOAD(R{q % depth}, {lit(real[q])})\n")
+                for h in part:
+                    if (int(hd[h, 0]) >> 8) == 2:                              # a barrier record of its own
+                        body.append(f"  tcc_barrier({'true' if int(hd[h, 5]) & 2 else 'false'});\n")
+                        continue
+                    q = pos[h]
+                    if W == 1 and (int(hd[h, 5]) & 4):
+                        # a new level: its records read what the level before wrote, through LDS, from OTHER lanes.  With
+                        # several wavefronts the step's barrier orders that; a single wavefront needs no barrier in
+                        # hardware (its LDS operations execute in order) but the COMPILER must not move a read above a
+                        # write it cannot see the dependence of -- measured: without this, mpc_dcmotor at depth 8 walks
+                        # 45 % of its instances into maxIter
+                        body.append("  __builtin_amdgcn_fence(__ATOMIC_RELEASE, \"wavefront\");\n"
+                                    "  __builtin_amdgcn_wave_barrier();\n"
+                                    "  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, \"wavefront\");\n")
+                    body.append(f"  TCC_EXEC(R{q % depth}, {lit(h)})\n")
+                    if q + depth < len(real):
+                        body.append(f"  TCC_LOAD(R{q % depth}, {lit(real[q + depth])})\n")
+                body.append("}\n")
+                w.append("".join(body))
+            calls[(rid, k)] = names
+    w.append("static __device__ __noinline__ void tc_ldsm_run(tc_lds lds, tc_gmem gm, const int rid) {\n"
+             "  const int lane = (int)(threadIdx.x & 63);\n"
+             "  const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));\n"
+             "  tc_block_sync();  // nobody may still be reading what this evaluation overwrites\n"
+             f"  switch (__builtin_amdgcn_readfirstlane(rid) * {W} + wave) {{\n")
+    for (rid, k), names in calls.items():
+        if names:
+            w.append(f"    case {rid * W + k}: " + " ".join(f"{nm}(lds, gm, lane);" for nm in names) + " break;\n")
+    w.append("    default: break;\n  }\n}\n\n")
+    return "".join(w)
+
+
+def emit_class_ldsm(spec, waves=4, stats=False, lds_slots=20000, fuse_chain=True, compiled=False):
     """body="ldsm": ONE instance per workgroup of `waves` wavefronts, hot state in LDS, the tape as data whose
     records give every lane a different scalar instruction (csrc/tc_ldsm.hip.inc, ldsm_schedule.py)."""
     from . import ldsm_schedule as lsch
@@ -1589,7 +1658,10 @@ def emit_class_ldsm(spec, waves=4, stats=False, lds_slots=20000, fuse_chain=True
                  for _, v in cs["consts"]) + "};\n"
              "static __device__ const int tc_const_addr[] = {" + ", ".join(str(int(a)) for a, _ in cs["consts"]) + "};\n"
              f"#define TC_NCONST {len(cs['consts'])}\n"
+             + ("#define TC_LDSC 1\n" if compiled else "") +
              '#include "tc_ldsm.hip.inc"\n\n')
+    if compiled:
+        w.append(_ldsc_functions(cs, W))
     for g, members in enumerate(T.groups, 1):
         w.append(f"// group {g}: {len(members)} instructions in {cs['gstats'][g][1]} levels, {int(T.flops[g].sum())} flops\n"
                  f"#define TC_CALL_GRP{g} tc_ldsm_run(c.m, c.gm, {cs['rid'][g]})\n")
@@ -1812,7 +1884,7 @@ def build_class(spec, fp_contract="fast", arch="gfx950", opt="-O3", block=64, fo
                 recip=False, fast_div=False, inline_max=0, reg_budget=150, scratch="auto", body="code",
                 waves=1, fuse=False, static_clean=False, forward=False, rcache=0, lds_state=0, share=False,
                 branch_free_tails=True, exact=False, stg_blocks=0, lds_slots=20000, ilp=False, fw_window=0, sched_every=0,
-                try_flags=(), refresh_outputs=False):
+                try_flags=(), refresh_outputs=False, compiled=False):
     """Emit <cls>.hip (+ <cls>.h, <cls>.tape) and compile lib<cls>.so with hipcc for gfx950.
     Mirrors the createGateway/compile step of cmex2optimizeCS.m:403-417.
 
@@ -1832,7 +1904,7 @@ def build_class(spec, fp_contract="fast", arch="gfx950", opt="-O3", block=64, fo
     kq.update(repr((cls, sorted(spec.defines.items()), [(n, tuple(sz)) for n, sz in spec.outputs], fp_contract, arch, opt, block,
                     stats, tag, tuple(extra_flags), roll, min_waves, lanes, recip, fast_div, inline_max, reg_budget, scratch,
                     body, waves, fuse, static_clean, forward, rcache, lds_state, share, branch_free_tails, exact, stg_blocks,
-                    lds_slots, ilp, fw_window, sched_every, tuple(try_flags), refresh_outputs, os.environ.get("TC_LDS_PAD_SLOTS", ""), os.environ.get("TC_STG_BATCH", ""), os.environ.get("TC_LDSM_FUSE", ""),
+                    lds_slots, ilp, fw_window, sched_every, tuple(try_flags), refresh_outputs, compiled, os.environ.get("TC_LDS_PAD_SLOTS", ""), os.environ.get("TC_STG_BATCH", ""), os.environ.get("TC_LDSM_FUSE", ""), os.environ.get("TC_LDSC_DEPTH", ""), os.environ.get("TC_LDSM_PACK_LOCALS", ""),
                     os.environ.get("TC_SWEEP_UNROLL", ""))).encode())
     for f_ in sorted(os.listdir(HERE)):
         if f_.endswith(".py"):
@@ -1849,7 +1921,8 @@ def build_class(spec, fp_contract="fast", arch="gfx950", opt="-O3", block=64, fo
     if body == "ldsm":
         if fp_contract != "off":
             raise ValueError("body='ldsm' is a bit-exact back-end: fp_contract='off'")
-        src, L = emit_class_ldsm(spec, waves=waves, stats=stats, lds_slots=lds_slots)      # TC_LDSM_FUSE=0: no fused walk
+        src, L = emit_class_ldsm(spec, waves=waves, stats=stats, lds_slots=lds_slots,      # TC_LDSM_FUSE=0: no fused walk
+                                 compiled=bool(compiled))
     else:
       src, L = emit_class(spec, fp_contract=fp_contract, block=block, stats=stats, roll=roll,
                         min_waves=min_waves, lanes=lanes, recip=recip, fast_div=fast_div, inline_max=inline_max,

@@ -31,6 +31,8 @@ operands of the dot opcodes).  Operand words are address*2+neg (neg: the operand
 """
 from __future__ import annotations
 
+import os
+
 import numpy as np
 
 from . import instructions as I
@@ -253,14 +255,61 @@ def assign_slots(T, defines, lds_slots=20000, stage=STAGE):
         if ex:
             blocks.append(ex)
         locals_[g] = lo
-    nLocal = max([len(v) for v in locals_.values()], default=0)
+    # Group-local values are packed by LIFE TIME inside their group (round 4): the walk is level by level, a value is
+    # written at its level and read at its readers' levels (a reader that expands a product into its factors,
+    # stream_levels, reads the factors at ITS level), so a slot is free for a value of a later level as soon as its
+    # occupant's last reader has run -- a barrier (W > 1) or the single wavefront's program order lies in between.  For
+    # mpc_quadcopter's factor + solves 11 463 values need 5 914 slots; what this frees takes the group's INPUTS into the
+    # LDS: before, 575 of its 800 levels waited for a value in HBM.  (TC_LDSM_PACK_LOCALS=0: one slot per value.)
+    pack_locals = os.environ.get("TC_LDSM_PACK_LOCALS", "1") != "0"
+    local_slot = {}
+    sizes = [0]
+    if pack_locals:
+        slvl, _ = stream_levels(T, True)
+        for g, lo in locals_.items():
+            if not lo:
+                continue
+            los = set(lo)
+            last = {i: slvl[i] for i in lo}
+            for i in T.groups[g - 1].tolist():
+                if not T.used[i]:
+                    continue
+                li = slvl[i]
+                for j in opl[ost[i - 1]:ost[i]]:
+                    if j in los:
+                        if li > last[j]:
+                            last[j] = li
+                        if _is_product(T, opl, ost, j):          # i may read j's factors instead of j
+                            for jj in opl[ost[j - 1]:ost[j]]:
+                                if jj in los and li > last[jj]:
+                                    last[jj] = li
+                    elif grp[j] == g and _is_product(T, opl, ost, j):
+                        for jj in opl[ost[j - 1]:ost[j]]:
+                            if jj in los and li > last[jj]:
+                                last[jj] = li
+            import heapq
+            free, busy, nxt = [], [], 0       # free slot numbers; (last level, slot) of occupied ones
+            for i in sorted(lo, key=lambda i_: (slvl[i_], i_)):
+                while busy and busy[0][0] < slvl[i]:
+                    heapq.heappush(free, heapq.heappop(busy)[1])
+                if free:
+                    q = heapq.heappop(free)
+                else:
+                    q = nxt
+                    nxt += 1
+                local_slot[i] = q
+                heapq.heappush(busy, (last[i], q))
+            sizes.append(nxt)
+        nLocal = max(sizes)
+    else:
+        nLocal = max([len(v) for v in locals_.values()], default=0)
     local_base = lds
     lds += nLocal
     stage_base = lds                             # terms of long instructions (build_stream), + 8: chunked reads
     lds += int(stage) + 8
     for g, lo in locals_.items():
         for q, i in enumerate(lo):
-            where[i] = local_base + q
+            where[i] = local_base + (local_slot[i] if pack_locals else q)
     # hot blocks into what is left of the LDS (each packed among themselves by life time), cold blocks to HBM
     L.share = defines
     L.ignore_dead_readers = True

@@ -100,7 +100,7 @@ def test_quadcopter_full_batch_properties():
     import torch
     from dense_ipm import quadcopter_model
     B = 512
-    spec, ds, st, it, out = _run("quadcopter", "ldsm8", B, seed0=0)
+    spec, ds, st, it, out = _run("quadcopter", "ldsc4", B, seed0=0)
     assert (st == 0).all() and it.max() <= 1000
     _replicas_equal(st, it, out, B)
     for k in (0, 41, 255):

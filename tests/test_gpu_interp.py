@@ -109,7 +109,7 @@ def test_sls_ldsm_bit_exact(libs, sls_spec, tmp_path, variant):
     assert np.array_equal(got, ref)
 
 
-@pytest.mark.parametrize("variant", ["dcmotor_ldsm4", "dcmotor_ldsm8", "dcmotor_ldsm_cold"])
+@pytest.mark.parametrize("variant", ["dcmotor_ldsm4", "dcmotor_ldsm8", "dcmotor_ldsm_cold", "dcmotor_ldsc", "dcmotor_ldsc4"])
 def test_dcmotor_ldsm_bit_exact(libs, tmp_path, variant):
     """nG > 0, second LDL; `ldsm_cold`: an LDS budget too small for the state, so part of it lives in the
     per-instance HBM array (global operand / destination path of the device walk)"""
@@ -161,7 +161,7 @@ def test_quadcopter_T100_ldsm_vs_interp_vs_oracle(libs, tmp_path):
     save_tape(spec.tape, tape)
     c = spec.classname
     res = {}
-    for tag in ("quadcopter_ldsm4", "quadcopter_ldsm8", "quadcopter_interp"):
+    for tag in ("quadcopter_ldsm4", "quadcopter_ldsm8", "quadcopter_ldsc4", "quadcopter_interp"):
         obj = _load(libs[tag], B)
         for n in names:
             obj.set(n, stacked[n])
@@ -175,6 +175,9 @@ def test_quadcopter_T100_ldsm_vs_interp_vs_oracle(libs, tmp_path):
             out = obj.getOutputs(as_dict=True)
         obj.close()
     a, b, a8 = res["quadcopter_ldsm4"], res["quadcopter_interp"], res["quadcopter_ldsm8"]
+    ac = res["quadcopter_ldsc4"]          # the compiled record walk: the same stream, printed instead of interpreted
+    print("ldsc4 %.0f ms" % (ac[3] * 1e3))
+    assert np.array_equal(ac[0], b[0]) and np.array_equal(ac[1], b[1]) and np.array_equal(ac[2], b[2], equal_nan=True)
     print("\nquadcopter T=100, B=64: ldsm4 %.0f ms, ldsm8 %.0f ms, interp %.0f ms; iterations %d..%d"
           % (a[3] * 1e3, a8[3] * 1e3, b[3] * 1e3, a[1].min(), a[1].max()))
     assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1]) and np.array_equal(a[2], b[2], equal_nan=True)

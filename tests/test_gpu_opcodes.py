@@ -19,7 +19,7 @@ def _ulps(a, b):
     return np.abs(a - b) / np.spacing(np.maximum(np.abs(a), np.abs(b)))
 
 
-@pytest.mark.parametrize("variant", ["strict", "w8x", "interp", "ldsm"])
+@pytest.mark.parametrize("variant", ["strict", "w8x", "interp", "ldsm", "ldsc"])
 def test_opcode_zoo(tmp_path, variant):
     import __graft_entry__ as g
     from tenscalc_amd.problems.small import opcode_zoo

@@ -31,7 +31,7 @@ def test_random_qp_lowerings_bitwise(libs, tmp_path, seed):
     ref, rst, rit = Oracle(tape).solve_batch({f"{c}_set_{n}": data[n] for n in names}, c + "_getOutputs", B,
                                              mu0=SOLVE_ARGS["mu0"], maxIter=SOLVE_ARGS["maxIter"])
     assert (rst == 0).mean() > .9             # the problems are feasible and convex: the solver converges
-    for v in ("strict", "w8x", "interp", "ldsm4"):
+    for v in ("strict", "w8x", "interp", "ldsm4", "ldsc4"):
         obj = HipSolver(libs["rqp%d_%s" % (seed, v)], B=B)
         for n in names:
             obj.set(n, data[n])
