@@ -10,7 +10,7 @@ import __graft_entry__ as g
 from tenscalc_amd.runtime import HipSolver
 
 rows = []
-for prob, variants in (("dcmotor", ["strict", "interp8", "ldsm8"]), ("l1l2", ["interp8", "ldsm8"]), ("quadcopter", ["interp8", "ldsm8"])):
+for prob, variants in (("dcmotor", ["strict", "interp8", "ldsm8", "ldsc"]), ("l1l2", ["interp8", "ldsm8", "ldsc4"]), ("quadcopter", ["interp8", "ldsm8", "ldsc4"])):
     if prob == "dcmotor":
         from tenscalc_amd.problems.mpc_dcmotor import SOLVE_ARGS, dcmotor_data as data_fn, mpc_dcmotor as mk
     elif prob == "l1l2":
