@@ -1,6 +1,6 @@
 """Tuning aid: one class library under several emitter keyword settings -- built in parallel (CPU container), timed and
 compared bit for bit with the first (GPU box).
-   python scripts/kw_sweep.py build|run <sls|dcmotor> <variant> <B> "k=v,k=v" "k=v" ...     ("" = the variant as it is)"""
+   python scripts/kw_sweep.py build|run <sls|dcmotor|l1l2|quadcopter> <variant> <B> "k=v,k=v" "k=v" ...     ("" = the variant as it is)"""
 import os
 import sys
 
@@ -14,6 +14,12 @@ sets = sys.argv[5:]
 if which == "sls":
     from tenscalc_amd.problems.sls import SOLVE_ARGS
     mk = lambda: g.sls_spec(variant)      # noqa: E731
+elif which == "l1l2":
+    from tenscalc_amd.problems.l1l2 import SOLVE_ARGS, l1l2, l1l2_data as data
+    mk = lambda: l1l2(folder=g.GENERATED)      # noqa: E731
+elif which == "quadcopter":
+    from tenscalc_amd.problems.mpc_quadcopter import SOLVE_ARGS, mpc_quadcopter, quadcopter_data as data
+    mk = lambda: mpc_quadcopter(folder=g.GENERATED)      # noqa: E731
 else:
     from tenscalc_amd.problems.mpc_dcmotor import SOLVE_ARGS, dcmotor_data as data, mpc_dcmotor
     mk = lambda: mpc_dcmotor(folder=g.GENERATED)      # noqa: E731
@@ -58,7 +64,7 @@ else:
                     obj.set(n, host[n])
             obj.synchronize()
             ts = []
-            for _ in range(10):
+            for _ in range(int(os.environ.get('TC_SWEEP_REPS', '10'))):
                 st_, it, tm = obj.solve(**SOLVE_ARGS)
                 ts.append(tm)
             out = np.concatenate([o.reshape(B, -1) for o in obj.getOutputs()], axis=1)

@@ -1519,7 +1519,7 @@ def emit_class(spec, fp_contract="fast", block=64, stats=False, roll=True, min_w
     return "".join(w), L
 
 
-def _ldsc_functions(cs, W, chunk=96, depth=8):
+def _ldsc_functions(cs, W, chunk=96, depth=8, trace=False):
     """body="ldsm", compiled=True: the record stream printed as code.  Per record range (a dependency group or a copy
     entry point) and per wavefront of the workgroup: its records in stream order, each one a TCC_EXEC with the header
     fields as literals (csrc/tc_ldsm.hip.inc: tcl_exec_t folds to the record's own code), its body words requested
@@ -1558,6 +1558,8 @@ def _ldsc_functions(cs, W, chunk=96, depth=8):
                     body.append(f"  TCC_LOAD(R{q % depth}, {lit(real[q])})\n")
                 for h in part:
                     if (int(hd[h, 0]) >> 8) == 2:                              # a barrier record of its own
+                        if trace and k == 0:
+                            body.append(f"  TCC_STAMP({h})\n")
                         body.append(f"  tcc_barrier({'true' if int(hd[h, 5]) & 2 else 'false'});\n")
                         continue
                     q = pos[h]
@@ -1570,6 +1572,8 @@ def _ldsc_functions(cs, W, chunk=96, depth=8):
                         body.append("  __builtin_amdgcn_fence(__ATOMIC_RELEASE, \"wavefront\");\n"
                                     "  __builtin_amdgcn_wave_barrier();\n"
                                     "  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, \"wavefront\");\n")
+                    if trace and k == 0 and (int(hd[h, 5]) & 4):
+                        body.append(f"  TCC_STAMP({h})\n")      # stats="levels": when wavefront 0 enters the level
                     body.append(f"  TCC_EXEC(R{q % depth}, {lit(h)})\n")
                     if q + depth < len(real):
                         body.append(f"  TCC_LOAD(R{q % depth}, {lit(real[q + depth])})\n")
@@ -1618,7 +1622,11 @@ def emit_class_ldsm(spec, waves=4, stats=False, lds_slots=20000, fuse_chain=True
              f"#define TC_NDIST 0\n#define TC_LDSM 1\n#define TC_W {W}\n#define TC_NLDS {cs['nLds']}\n#define TC_NGLOB {max(1, cs['nGlob'])}\n"
              f"#define TC_LAUNCH_BOUNDS __launch_bounds__(TC_BLOCK)\n")
     if stats:
-        w.append("#define TC_STATS %d\n" % (2 if stats == "phases" else 1))
+        # stats="levels" (compiled walk only): wavefront 0 of block 0 writes (record, clock) into the dbg buffer whenever
+        # it enters a level; the cursor lives in the last padding slot of the staging area (scripts/level_trace.py)
+        w.append("#define TC_STATS %d\n" % ({"phases": 2, "levels": 4}.get(stats, 1)))
+        if stats == "levels":
+            w.append(f"#define TCC_CUR_SLOT {int(cs['stage_base']) + int(cs['nStage']) + 7}   // read padding of the staging area: never written\n")
     w.append(_define_block(spec))
     nOut = cs["nOut"]
     w.append(f"#define TC_NM {cs['nLds']}\n#define TC_NMP {cs['nLds']}\n#define TC_NEXT {cs['nExt']}\n#define TC_NOUT {nOut}\n"
@@ -1661,7 +1669,12 @@ def emit_class_ldsm(spec, waves=4, stats=False, lds_slots=20000, fuse_chain=True
              + ("#define TC_LDSC 1\n" if compiled else "") +
              '#include "tc_ldsm.hip.inc"\n\n')
     if compiled:
-        w.append(_ldsc_functions(cs, W))
+        if stats == "levels":
+            w.append("static __device__ double *tcc_dbg;\nstatic __device__ long tcc_dbg_n;\n"
+                     "#define TCC_STAMP(h) if (blockIdx.x == 0 && lane == 0) { \\\n"
+                     "    __attribute__((address_space(3))) long long *q_ = (__attribute__((address_space(3))) long long *)&lds[TCC_CUR_SLOT]; \\\n"
+                     "    const long long n_ = *q_; if (n_ < tcc_dbg_n) { tcc_dbg[2 * n_] = (double)(h); tcc_dbg[2 * n_ + 1] = (double)clock64(); *q_ = n_ + 1; } }\n")
+        w.append(_ldsc_functions(cs, W, trace=(stats == "levels")))
     for g, members in enumerate(T.groups, 1):
         w.append(f"// group {g}: {len(members)} instructions in {cs['gstats'][g][1]} levels, {int(T.flops[g].sum())} flops\n"
                  f"#define TC_CALL_GRP{g} tc_ldsm_run(c.m, c.gm, {cs['rid'][g]})\n")
@@ -1737,6 +1750,9 @@ def emit_class_ldsm(spec, waves=4, stats=False, lds_slots=20000, fuse_chain=True
              "  for (int k = 0; k < 8; k++) c.ph[k] = 0;\n  const long long tstart_ = clock64();\n  c.tph = tstart_;\n#endif\n"
              "  for (int k = threadIdx.x; k < TC_NCONST; k += TC_BLOCK) c.m[tc_const_addr[k]] = tc_consts[k];\n"
              "  if (threadIdx.x == 0) c.m[0] = 0.0;\n"
+             + ("  if (threadIdx.x == 0) { *(__attribute__((address_space(3))) long long *)&c.m[TCC_CUR_SLOT] = 0; "
+                "if (blockIdx.x == 0) { tcc_dbg = dbg; tcc_dbg_n = ((long)(2 * TC_NGROUPS + 10) * B) / 2; } }\n"
+                if stats == "levels" else "") +
              "  __syncthreads();\n"
              "  int st = 0, it = 0;\n"
              "  TC_SOLVER_SYMBOL(c, mu0, maxIter, ae0, ae1, &st, &it);\n"
@@ -1744,7 +1760,8 @@ def emit_class_ldsm(spec, waves=4, stats=False, lds_slots=20000, fuse_chain=True
              f"  for (int j = threadIdx.x; j < TC_NOUT; j += TC_BLOCK) {{ const int a = tc_code[{cs['out_off']} + j]; "
              "O[(long)j * B + tid] = TCL_LD(a); }\n"
              "  if (threadIdx.x == 0) { status[tid] = st; iter[tid] = it; }\n"
-             "#ifdef TC_STATS\n  if (dbg && threadIdx.x == 0) {\n"
+             + ("#if 0   // stats=\"levels\": the dbg buffer holds the stamps\n" if stats == "levels" else "#ifdef TC_STATS\n") +
+             "  if (dbg && threadIdx.x == 0) {\n"
              "    for (int k = 0; k < TC_NGROUPS; k++) {\n"
              "      dbg[(long)k * B + tid] = (double)c.cyc[k];\n      dbg[(long)(TC_NGROUPS + k) * B + tid] = (double)c.cnt[k];\n    }\n"
              "    dbg[(long)(2 * TC_NGROUPS) * B + tid] = (double)(clock64() - tstart_);\n"
