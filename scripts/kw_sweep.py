@@ -29,9 +29,19 @@ def build(st):
     kw = dict(g.VARIANT_KW[variant])
     for kv in [x for x in st.split(",") if x]:
         k, v = kv.split("=")
+        if k == "E":          # E=NAME:VALUE -> environment variable of the emitter (hashed into the build key)
+            os.environ[v.split(":")[0]] = v.split(":")[1]
+            continue
+        if k == "D":          # D=NAME:VALUE -> -DNAME=VALUE (diagnostic builds, e.g. D=TCL_DUP_CHAIN:2)
+            kw["extra_flags"] = tuple(kw.get("extra_flags", ())) + ("-D" + v.replace(":", "="),)
+            continue
         kw[k] = int(v) if v.lstrip('-').isdigit() else v
-    kw["tag"] = variant + "_k" + st.replace("=", "").replace(",", "_")
-    return st, mk().build(**kw)
+    kw["tag"] = variant + "_k" + st.replace("=", "").replace(",", "_").replace(":", "")
+    try:
+        return st, mk().build(**kw)
+    finally:
+        for kv in [x for x in st.split(",") if x.startswith("E=")]:
+            os.environ.pop(kv[2:].split(":")[0], None)
 
 
 if mode == "build":

@@ -86,18 +86,31 @@ for rid in range(nrid):
                     late = (int(hd[h, 5]) >> 3) & 3 if kind == 3 else 0
                     sig.append((kindname[kind], opname.get(op, str(op)), int(hd[h, 1]), int(hd[h, 3]), late, bool(hd[h, 5] & 3)))
         steps_of[per[0][s][0]] = sig
-dur = np.diff(clk)
+ph, rec = rec & 7, rec >> 3
 agg = defaultdict(list)
-for q in range(nst - 1):
-    sig = steps_of.get(int(rec[q]))
-    if sig is None:
+q = 0
+while q < nst - 1:
+    if ph[q] != 0:
+        q += 1
         continue
-    kinds = sorted({"%s:%s%s%s" % (a, b.replace("I_", ""), "+late" if e else "", "+hbm" if f else "") for a, b, c, d, e, f in sig})
-    nrec = len(sig)
-    mx = max([c for a, b, c, d, e, f in sig if a == "fold"] + [0])
-    agg[(" ".join(kinds) or "(empty)", min(nrec, 9), (mx + 7) // 8 * 8)].append(dur[q])
-tot = float(dur.sum())
-print("total stamped cycles %.3g over %d steps: %.0f per step" % (tot, nst - 1, tot / max(1, nst - 1)))
-print("%-70s %5s %6s %8s %8s %6s" % ("step holds", "recs", "fold<=", "steps", "median", "share"))
-for key, v in sorted(agg.items(), key=lambda kv: -sum(kv[1]))[:40]:
-    print("%-70s %5d %6d %8d %8.0f %5.1f%%" % (key[0][:70], key[1], key[2], len(v), float(np.median(v)), 100 * sum(v) / tot))
+    e = q + 1
+    while e < nst and ph[e] != 0:
+        e += 1
+    if e >= nst:
+        break
+    t = {int(ph[j]): clk[j] for j in range(q, e)}
+    sig = steps_of.get(int(rec[q]))
+    if sig is not None:
+        kinds = sorted({"%s:%s%s%s" % (a, b.replace("I_", ""), "+late" if e_ else "", "+hbm" if f else "") for a, b, c, d, e_, f in sig})
+        mx = max([c for a, b, c, d, e_, f in sig if a == "fold"] + [0])
+        row = [clk[e] - clk[q], t.get(1, np.nan) - t[0], t.get(2, np.nan) - t.get(1, np.nan), t.get(3, np.nan) - t.get(2, np.nan),
+               clk[e] - t.get(3, t.get(2, t[0]))]
+        agg[(" ".join(kinds) or "(empty)", min(len(sig), 9), (mx + 7) // 8 * 8)].append(row)
+    q = e
+tot = sum(r[0] for v in agg.values() for r in v)
+nsteps = sum(len(v) for v in agg.values())
+print("total stamped cycles %.3g over %d steps: %.0f per step (each phase includes one stamp: two LDS reads, clock, store)" % (tot, nsteps, tot / max(1, nsteps)))
+print("%-58s %4s %5s %6s %6s | %6s %6s %6s %6s %6s" % ("step holds (all wavefronts)", "recs", "fold<=", "steps", "share", "total", "gather", "finish", "barrier", "tail"))
+for key, v in sorted(agg.items(), key=lambda kv: -sum(r[0] for r in kv[1]))[:40]:
+    m_ = np.nanmedian(np.asarray(v, dtype=float), axis=0)
+    print("%-58s %4d %5d %6d %5.1f%% | %6.0f %6.0f %6.0f %6.0f %6.0f" % (key[0][:58], key[1], key[2], len(v), 100 * sum(r[0] for r in v) / tot, *m_))

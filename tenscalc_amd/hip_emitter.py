@@ -1520,6 +1520,11 @@ def emit_class(spec, fp_contract="fast", block=64, stats=False, roll=True, min_w
 
 
 def _ldsc_functions(cs, W, chunk=96, depth=8, trace=False):
+    from . import instructions as I
+    from . import ldsm_schedule as lsch
+    two_phase = os.environ.get("TC_LDSC_TWO_PHASE", "1") != "0"
+    split_hbm = os.environ.get("TC_LDSC_SPLIT_HBM", "1") != "0"     # tuning aids (hashed into the build key)
+    sched_b = os.environ.get("TC_LDSC_SCHEDB", "0") != "0"          # measured: 202.3 ms with, 200.9 without (quadcopter, 512)
     """body="ldsm", compiled=True: the record stream printed as code.  Per record range (a dependency group or a copy
     entry point) and per wavefront of the workgroup: its records in stream order, each one a TCC_EXEC with the header
     fields as literals (csrc/tc_ldsm.hip.inc: tcl_exec_t folds to the record's own code), its body words requested
@@ -1556,14 +1561,42 @@ def _ldsc_functions(cs, W, chunk=96, depth=8, trace=False):
                 pos = {h: q for q, h in enumerate(real)}
                 for q in range(min(depth, len(real))):
                     body.append(f"  TCC_LOAD(R{q % depth}, {lit(real[q])})\n")
+                # steps of this wavefront: a record flagged "new level" opens one; a barrier record is one of its own;
+                # at most `depth` records each (a record and the one `depth` behind it share a register set)
+                steps, cur = [], None
                 for h in part:
-                    if (int(hd[h, 0]) >> 8) == 2:                              # a barrier record of its own
-                        if trace and k == 0:
-                            body.append(f"  TCC_STAMP({h})\n")
-                        body.append(f"  tcc_barrier({'true' if int(hd[h, 5]) & 2 else 'false'});\n")
+                    if (int(hd[h, 0]) >> 8) == 2:
+                        steps.append([h])
+                        cur = None
                         continue
-                    q = pos[h]
-                    if W == 1 and (int(hd[h, 5]) & 4):
+                    if cur is None or (int(hd[h, 5]) & 4) or len(cur) >= depth:
+                        cur = []
+                        steps.append(cur)
+                    cur.append(h)
+
+                def splittable(h):
+                    """tc_ldsm.hip.inc, "two-phase records": LDS-only SHORT records; LDS-only ordered sums of up to
+                    TCL_FOLD_ALL (48) staged terms whose late terms, if any, follow the chain"""
+                    kind, op, fl = int(hd[h, 0]) >> 8, int(hd[h, 0]) & 255, int(hd[h, 5])
+                    if not two_phase:
+                        return False
+                    if kind == 1:
+                        return split_hbm or not (fl & 3)     # also with operands / results in HBM: the loads of a step together
+                    if fl & 3:
+                        return False
+                    dots = (I.I_minus_dot, I.I_minus_dot_div, I.I_plus_minus_dot, I.I_plus_minus_dot_div)
+                    if kind == 3 and int(hd[h, 1]) <= 48 and (op in dots or op == lsch.F_SUM):
+                        nlm = (fl >> lsch.F_NLATE_SHIFT) & 3
+                        return nlm == 0 or (op in dots and bool(int(hd[h, 2]) & lsch.LATE_LAST))
+                    return False
+                for st in steps:
+                    h0_ = st[0]
+                    if (int(hd[h0_, 0]) >> 8) == 2:                              # a barrier record of its own
+                        if trace and k == 0:
+                            body.append(f"  TCC_STAMP({h0_ * 8})\n")
+                        body.append(f"  tcc_barrier({'true' if int(hd[h0_, 5]) & 2 else 'false'});\n")
+                        continue
+                    if W == 1 and (int(hd[h0_, 5]) & 4):
                         # a new level: its records read what the level before wrote, through LDS, from OTHER lanes.  With
                         # several wavefronts the step's barrier orders that; a single wavefront needs no barrier in
                         # hardware (its LDS operations execute in order) but the COMPILER must not move a read above a
@@ -1572,11 +1605,38 @@ def _ldsc_functions(cs, W, chunk=96, depth=8, trace=False):
                         body.append("  __builtin_amdgcn_fence(__ATOMIC_RELEASE, \"wavefront\");\n"
                                     "  __builtin_amdgcn_wave_barrier();\n"
                                     "  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, \"wavefront\");\n")
-                    if trace and k == 0 and (int(hd[h, 5]) & 4):
-                        body.append(f"  TCC_STAMP({h})\n")      # stats="levels": when wavefront 0 enters the level
-                    body.append(f"  TCC_EXEC(R{q % depth}, {lit(h)})\n")
-                    if q + depth < len(real):
-                        body.append(f"  TCC_LOAD(R{q % depth}, {lit(real[q + depth])})\n")
+                    tr = trace and k == 0 and bool(int(hd[h0_, 5]) & 4)
+                    if tr:
+                        body.append(f"  TCC_STAMP({h0_ * 8})\n")      # stats="levels": when wavefront 0 enters the level
+                    sp = [h for h in st if splittable(h)]
+                    # folds first: theirs is the step's longest chain
+                    sp.sort(key=lambda h: 0 if (int(hd[h, 0]) >> 8) == 3 else 1)
+                    body.append("  {\n")
+                    for h in sp:
+                        body.append(f"    double G{pos[h] % depth}[TCL_NG];\n    TCC_GATHER(R{pos[h] % depth}, G{pos[h] % depth}, {lit(h)})\n")
+                    for h in st:
+                        if h not in sp:
+                            body.append(f"    TCC_RUN(R{pos[h] % depth}, {lit(h)})\n")
+                    if tr:       # ... has its operands (forced wait) / has stored its results / is through the barrier
+                        body.append(f"    asm volatile(\"s_waitcnt lgkmcnt(0)\" ::: \"memory\");\n    TCC_STAMP({h0_ * 8 + 1})\n")
+                    if sp and sched_b:
+                        # every load of the step before any of its arithmetic: left alone the scheduler sinks the late
+                        # operands' loads to their use, behind the chain -- one more LDS latency on the step's critical path
+                        body.append("    __builtin_amdgcn_sched_barrier(0);\n")
+                    for h in sp:
+                        body.append(f"    TCC_FINISH(R{pos[h] % depth}, G{pos[h] % depth}, {lit(h)})\n")
+                    if tr:
+                        body.append(f"    asm volatile(\"s_waitcnt lgkmcnt(0)\" ::: \"memory\");\n    TCC_STAMP({h0_ * 8 + 2})\n")
+                    body.append("  }\n")
+                    bar = [h for h in st if int(hd[h, 5]) & 64]
+                    if bar:
+                        body.append(f"  tcc_barrier({'true' if any(int(hd[h, 5]) & 128 for h in bar) else 'false'});\n")
+                        if tr:
+                            body.append(f"  TCC_STAMP({h0_ * 8 + 3})\n")
+                    for h in st:
+                        q = pos[h]
+                        if q + depth < len(real):
+                            body.append(f"  TCC_LOAD(R{q % depth}, {lit(real[q + depth])})\n")
                 body.append("}\n")
                 w.append("".join(body))
             calls[(rid, k)] = names
@@ -1670,10 +1730,12 @@ def emit_class_ldsm(spec, waves=4, stats=False, lds_slots=20000, fuse_chain=True
              '#include "tc_ldsm.hip.inc"\n\n')
     if compiled:
         if stats == "levels":
-            w.append("static __device__ double *tcc_dbg;\nstatic __device__ long tcc_dbg_n;\n"
+            w.append("// (cursor, buffer and its size live in three padding slots of the staging area: a stamp is two LDS reads, a\n"
+                     "// clock read, one store -- no global load)\n"
                      "#define TCC_STAMP(h) if (blockIdx.x == 0 && lane == 0) { \\\n"
-                     "    __attribute__((address_space(3))) long long *q_ = (__attribute__((address_space(3))) long long *)&lds[TCC_CUR_SLOT]; \\\n"
-                     "    const long long n_ = *q_; if (n_ < tcc_dbg_n) { tcc_dbg[2 * n_] = (double)(h); tcc_dbg[2 * n_ + 1] = (double)clock64(); *q_ = n_ + 1; } }\n")
+                     "    __attribute__((address_space(3))) long long *q_ = (__attribute__((address_space(3))) long long *)&lds[TCC_CUR_SLOT - 2]; \\\n"
+                     "    const long long n_ = q_[2], lim_ = q_[1]; double *b_ = (double *)q_[0]; \\\n"
+                     "    if (n_ < lim_) { b_[2 * n_] = (double)(h); b_[2 * n_ + 1] = (double)clock64(); q_[2] = n_ + 1; } }\n")
         w.append(_ldsc_functions(cs, W, trace=(stats == "levels")))
     for g, members in enumerate(T.groups, 1):
         w.append(f"// group {g}: {len(members)} instructions in {cs['gstats'][g][1]} levels, {int(T.flops[g].sum())} flops\n"
@@ -1750,8 +1812,8 @@ def emit_class_ldsm(spec, waves=4, stats=False, lds_slots=20000, fuse_chain=True
              "  for (int k = 0; k < 8; k++) c.ph[k] = 0;\n  const long long tstart_ = clock64();\n  c.tph = tstart_;\n#endif\n"
              "  for (int k = threadIdx.x; k < TC_NCONST; k += TC_BLOCK) c.m[tc_const_addr[k]] = tc_consts[k];\n"
              "  if (threadIdx.x == 0) c.m[0] = 0.0;\n"
-             + ("  if (threadIdx.x == 0) { *(__attribute__((address_space(3))) long long *)&c.m[TCC_CUR_SLOT] = 0; "
-                "if (blockIdx.x == 0) { tcc_dbg = dbg; tcc_dbg_n = ((long)(2 * TC_NGROUPS + 10) * B) / 2; } }\n"
+             + ("  if (threadIdx.x == 0) { __attribute__((address_space(3))) long long *q_ = (__attribute__((address_space(3))) long long *)&c.m[TCC_CUR_SLOT - 2]; "
+                "q_[0] = (long long)dbg; q_[1] = ((long long)(2 * TC_NGROUPS + 10) * B) / 2; q_[2] = 0; }\n"
                 if stats == "levels" else "") +
              "  __syncthreads();\n"
              "  int st = 0, it = 0;\n"
@@ -1896,6 +1958,23 @@ def class_header(spec):
     return s
 
 
+def _deps_of(src):
+    """the csrc / include files a class source reads, found by following its #include "..." lines (sorted)"""
+    import re
+    seen, todo = {}, re.findall(r'^\s*#include "([^"]+)"', src, flags=re.M)
+    while todo:
+        nm = todo.pop()
+        if nm in seen:
+            continue
+        for base in (CSRC, INCLUDE):
+            p_ = os.path.join(base, nm)
+            if os.path.exists(p_):
+                seen[nm] = p_
+                todo += re.findall(r'^\s*#include "([^"]+)"', open(p_).read(), flags=re.M)
+                break
+    return [seen[k] for k in sorted(seen)]
+
+
 def build_class(spec, fp_contract="fast", arch="gfx950", opt="-O3", block=64, force=False,
                 outdir=None, stats=False, tag=None, extra_flags=(), roll=True, min_waves=0, lanes=1,
                 recip=False, fast_div=False, inline_max=0, reg_budget=150, scratch="auto", body="code",
@@ -1921,7 +2000,7 @@ def build_class(spec, fp_contract="fast", arch="gfx950", opt="-O3", block=64, fo
     kq.update(repr((cls, sorted(spec.defines.items()), [(n, tuple(sz)) for n, sz in spec.outputs], fp_contract, arch, opt, block,
                     stats, tag, tuple(extra_flags), roll, min_waves, lanes, recip, fast_div, inline_max, reg_budget, scratch,
                     body, waves, fuse, static_clean, forward, rcache, lds_state, share, branch_free_tails, exact, stg_blocks,
-                    lds_slots, ilp, fw_window, sched_every, tuple(try_flags), refresh_outputs, compiled, os.environ.get("TC_LDS_PAD_SLOTS", ""), os.environ.get("TC_STG_BATCH", ""), os.environ.get("TC_LDSM_FUSE", ""), os.environ.get("TC_LDSC_DEPTH", ""), os.environ.get("TC_LDSM_PACK_LOCALS", ""),
+                    lds_slots, ilp, fw_window, sched_every, tuple(try_flags), refresh_outputs, compiled, os.environ.get("TC_LDS_PAD_SLOTS", ""), os.environ.get("TC_STG_BATCH", ""), os.environ.get("TC_LDSM_FUSE", ""), os.environ.get("TC_LDSC_DEPTH", ""), os.environ.get("TC_LDSM_PACK_LOCALS", ""), os.environ.get("TC_LDSM_ROW_SKEW", ""), os.environ.get("TC_LDSM_LATE_LAST", ""), os.environ.get("TC_LDSC_TWO_PHASE", ""), os.environ.get("TC_LDSC_SPLIT_HBM", ""), os.environ.get("TC_LDSC_SCHEDB", ""),
                     os.environ.get("TC_SWEEP_UNROLL", ""))).encode())
     for f_ in sorted(os.listdir(HERE)):
         if f_.endswith(".py"):
@@ -1951,17 +2030,10 @@ def build_class(spec, fp_contract="fast", arch="gfx950", opt="-O3", block=64, fo
     so = os.path.join(outdir, f"lib{cls}{suffix}.so")
     flags = [opt, f"--offload-arch={arch}", "-fPIC", "-shared", "-std=c++17",
              f"-ffp-contract={fp_contract}", "-I", CSRC, "-I", INCLUDE, "-Wno-unused-value"] + list(extra_flags)
-    deps = [os.path.join(CSRC, "ipm_newton_eq.hip.inc" if _solver_of(spec) == "ipmPDeq_CSsolver" else "ipm_newton.hip.inc"),
-            os.path.join(CSRC, "tc_runtime.hip.inc"),
-            os.path.join(CSRC, "tc_wave.hip.inc"), os.path.join(CSRC, "tc_interp.hip.inc"),
-            os.path.join(CSRC, "tc_ldsm.hip.inc"), os.path.join(CSRC, "tc_pow.hip.inc"),
-            os.path.join(CSRC, "tc_glibcpow.hip.inc"), os.path.join(CSRC, "tc_glibcpow_tables.inc"),
-            os.path.join(CSRC, "tc_crmath.hip.inc"),
-            os.path.join(INCLUDE, "tenscalc_hip.h")]
     # (the digest must not depend on where the tree lies: the libraries built here travel to the GPU box, whose
     # checkout is at another path -- with the include directories hashed in, every library was rebuilt there)
     h = hashlib.sha256((src + " ".join(f for f in flags + list(try_flags) if f not in (CSRC, INCLUDE))).encode())
-    for d in deps:
+    for d in _deps_of(src):          # the files this class includes, directly or not: an edit rebuilds only its readers
         h.update(open(d, "rb").read())
     stamp = os.path.join(outdir, f"{cls}{suffix}.stamp")
     digest = h.hexdigest()

@@ -54,6 +54,9 @@ F_GLOBAL_SRC, F_GLOBAL_DST, F_NEW_LEVEL = 1, 2, 4
 F_NLATE_SHIFT = 3      # flags bits 3-4 of a FOLD record: the largest late-term count among its lanes
 F_PADDED = 32          # FOLD record: every row is padded to a multiple of 8 terms with the operation's identity
 F_BARRIER_AFTER = 64   # the step ends behind this record: workgroup barrier (W > 1), saves a barrier record
+LATE_LAST = 1 << 20    # aux bit of a dot FOLD record: the late terms are the LAST terms of every row -- they are not staged;
+                       # the lane folds the (padded) early terms and adds the late products behind them.  x + (-0.0) is x,
+                       # so "early, pads, late" is "early, late, pads": the reference's chain
 F_BARRIER_GLOBAL = 128  # ... and the step wrote to the instance's HBM array: the barrier must order those stores too
 _DOT_SKIP = {I.I_minus_dot: 0, I.I_minus_dot_div: 1, I.I_plus_minus_dot: 1, I.I_plus_minus_dot_div: 2}
 _LONG_OPS = {I.I_sum, I.I_sumprod, I.I_plus_sqr, I.I_plus_abs, I.I_min, I.I_min0, I.I_max, I.I_max0,
@@ -506,7 +509,13 @@ def build_stream(T, addr, nLds, W=1, stage_base=None, nStage=0, hoist=True, pads
         if s_.get("split"):
             cks = chunks_of(s_)
             return sum(up8(ln) for _, ln in cks) + up8(len(cks) + (1 if _SPLIT[s_["fop"]][1] else 0))
-        return up8(n_) if s_["fop"] in _PADDED_FOPS else n_
+        # + SKEW: rows padded to multiples of 8 doubles all start on the same two LDS banks (64-byte granules of a
+        # 128-byte bank period), and the lanes of a fold record read THEIR rows with the same instruction: ten rows, a
+        # five-way conflict on every read of the chain.  Two doubles between rows spread the starts over all banks
+        # (measured on mpc_quadcopter: a fold step cost 36 cycles per term -- 8 of them the addition).
+        return (up8(n_) if s_["fop"] in _PADDED_FOPS else n_) + SKEW
+    SKEW = int(os.environ.get("TC_LDSM_ROW_SKEW", "2"))
+    LATE_LAST_ON = os.environ.get("TC_LDSM_LATE_LAST", "1") != "0"
     # staging area = two alternating halves for terms computed one step ahead + the classic region, which must hold
     # the longest staged instruction of the class
     longest = 0
@@ -516,7 +525,7 @@ def build_stream(T, addr, nLds, W=1, stage_base=None, nStage=0, hoist=True, pads
             tn = int(T.pars[T.parStart[i - 1]]) if op == I.I_sumprod else (_TERM[op][1] if op in _TERM else 1)
             nt = (ost[i] - ost[i - 1] - _DOT_SKIP.get(op, 0)) // max(tn, 1)
             fop = I.I_sumprod if op == I.I_sumprod else (_TERM[op][2] if op in _TERM else None)
-            sz = _staged_size(fop, tn, nt, split)
+            sz = _staged_size(fop, tn, nt, split) + SKEW
             if sz <= nStage:
                 longest = max(longest, sz)
     half = (max(0, nStage - longest) // 2) // 8 * 8 if hoist else 0
@@ -550,6 +559,11 @@ def build_stream(T, addr, nLds, W=1, stage_base=None, nStage=0, hoist=True, pads
                     first = False
                 if W > 1 and not per[k]:
                     streams[k].append(("barrier", gdst))    # a wave without work in this step only waits
+
+        # what a fold record costs its wavefront next to a short one (nn + 6), in the same unit: the level trace of
+        # mpc_quadcopter (scripts/level_trace.py) puts a step of one short record at ~600 cycles and a fold of 24 terms
+        # with late terms at ~1 300 -- the wavefront that folds should get nothing else until the others hold three shorts
+        FOLD_COST = lambda nn, it: it[1][0] + 30       # noqa: E731
 
         def cut(groups_, kind, cost):
             recs = []
@@ -608,7 +622,7 @@ def build_stream(T, addr, nLds, W=1, stage_base=None, nStage=0, hoist=True, pads
                     top, tn, fop = _TERM[op]
                 skip = _DOT_SKIP.get(op, 0)
                 nterm = (len(a) - skip) // tn
-                if nStage and tn <= NSHORT and _staged_size(fop, aux, nterm, split) <= cstage and (len(a) - skip) % tn == 0:
+                if nStage and tn <= NSHORT and _staged_size(fop, aux, nterm, split) + SKEW <= cstage and (len(a) - skip) % tn == 0:
                     tl, late = [], []
                     for q in range(nterm):
                         ids = list(ops[skip + q * tn:skip + (q + 1) * tn])
@@ -654,15 +668,25 @@ def build_stream(T, addr, nLds, W=1, stage_base=None, nStage=0, hoist=True, pads
                 hoist = False
             info.append(dict(short=short, long_=long_, staged=staged, hoist=hoist))
 
+        def late_last(s_):
+            """the row's late terms are its last terms (or it has none) and it is an ordered sum of products"""
+            lt = [q for q, x in enumerate(s_["late"]) if x]
+            n_ = len(s_["terms"])
+            return (LATE_LAST_ON and s_["fop"] in _DOT_SKIP and not s_.get("split") and n_ - len(lt) >= 1
+                    and lt == list(range(n_ - len(lt), n_)))
+
         def fold_item(s_, base, inline):
             hw = [s_["heads"][q] if q < len(s_["heads"]) else 2 for q in range(2)]
             body = [len(s_["terms"]), hw[0], hw[1], base]
             if inline:
                 lt = [q for q, x in enumerate(s_["late"]) if x]
+                ll = late_last(s_)
+                if ll:
+                    body[0] -= len(lt)      # the chain runs over the early terms; the late products follow it
                 body.append(len(lt))
                 for q in range(NLATE):      # position, a, b, c: the term is a * (b * c)
                     tw = s_["terms"][lt[q]] if q < len(lt) else [2, 2]
-                    body += [lt[q] if q < len(lt) else 0, tw[0], tw[1], tw[2] if len(tw) == 3 else one * 2]
+                    body += [lt[q] if q < len(lt) and not ll else 0, tw[0], tw[1], tw[2] if len(tw) == 3 else one * 2]
             return (s_["d"], body)
 
         def term_key(s_, tw):
@@ -677,8 +701,11 @@ def build_stream(T, addr, nLds, W=1, stage_base=None, nStage=0, hoist=True, pads
                 for q in range(n_, up8(n_)):
                     terms.setdefault((OP_COPY, 1, 0), []).append((base + q, [pads[_PADDED_FOPS[fop]] * 2]))
 
-        def add_pads(terms, s_, base):
-            pad_row(terms, s_["fop"], base, len(s_["terms"]))
+        def add_pads(terms, s_, base, hoisted=False):
+            n_ = len(s_["terms"])
+            if hoisted and late_last(s_):
+                n_ -= sum(s_["late"])       # the late slots are never written: the identity from the first of them on
+            pad_row(terms, s_["fop"], base, n_)
         toggle = 0               # which staging half the next hoisted level's early terms go to
         for idx, lv in enumerate(info):
             recs = cut(lv["short"], K_SHORT, lambda nn, it: nn + 6) + cut(lv["long_"], K_LONG, lambda nn, it: len(it[1]) + 8)
@@ -693,7 +720,7 @@ def build_stream(T, addr, nLds, W=1, stage_base=None, nStage=0, hoist=True, pads
                     for q, tw in enumerate(s_["terms"]):
                         if not s_["late"][q]:
                             terms.setdefault(term_key(s_, tw), []).append((s_["base"] + q, tw))
-                    add_pads(terms, s_, s_["base"])
+                    add_pads(terms, s_, s_["base"], True)
                     used += rowlen(s_)             # the late terms keep their slot in the row: the folding lane fills it
                 if used > half:
                     raise AssertionError("staging half overflow")
@@ -702,10 +729,11 @@ def build_stream(T, addr, nLds, W=1, stage_base=None, nStage=0, hoist=True, pads
             if lv["hoist"]:
                 folds = {}
                 for s_ in staged:
-                    folds.setdefault((s_["fop"], 0, s_["aux"]), []).append(fold_item(s_, s_["base"], True))
+                    folds.setdefault((s_["fop"], 0, s_["aux"] | (LATE_LAST if late_last(s_) else 0)), []).append(
+                        fold_item(s_, s_["base"], True))
                 for key, items in folds.items():
                     folds[key] = sorted(items, key=lambda it: -it[1][0])
-                emit(recs + cut(folds, K_FOLD, lambda nn, it: it[1][0] // 2 + 8) + ahead_next)
+                emit(recs + cut(folds, K_FOLD, FOLD_COST) + ahead_next)
             elif not staged:
                 emit(recs + ahead_next)
             else:
@@ -748,10 +776,10 @@ def build_stream(T, addr, nLds, W=1, stage_base=None, nStage=0, hoist=True, pads
                     for key, items in folds.items():
                         folds[key] = sorted(items, key=lambda it: -it[1][0])
                     last = k0 >= len(staged)
-                    emit(cut(folds, K_FOLD, lambda nn, it: it[1][0] // 2 + 8) + cut(extra, K_SHORT, lambda nn, it: nn + 6)
+                    emit(cut(folds, K_FOLD, FOLD_COST) + cut(extra, K_SHORT, lambda nn, it: nn + 6)
                          + (ahead_next if last and not finals else []))
                     if finals:
-                        emit(cut(finals, K_FOLD, lambda nn, it: it[1][0] // 2 + 8) + (ahead_next if last else []))
+                        emit(cut(finals, K_FOLD, FOLD_COST) + (ahead_next if last else []))
                     if last:
                         break
         rg = []
@@ -842,7 +870,8 @@ def record_accesses(words, hdr):
             rd.add(int(body[3][q]) >> 1)
             if nlm:
                 for t in range(int(body[5][q])):
-                    wr.add(base + int(body[6 + 4 * t][q]))
+                    if not (aux & LATE_LAST and op in _DOT_SKIP):
+                        wr.add(base + int(body[6 + 4 * t][q]))
                     rd.update(int(body[7 + 4 * t + j][q]) >> 1 for j in range(3))
     else:
         skip = _DOT_SKIP.get(op, 0)

@@ -109,17 +109,23 @@ class Machine:
                     res.append(_term(op, aux, [m[x >> 1] for x in ws], [x & 1 for x in ws]))
             elif kind == lsch.K_FOLD:
                 ln, h0, h1, base = rows(1), rows(2), rows(3), rows(4)
+                llast = bool(aux & lsch.LATE_LAST) and op in lsch._DOT_SKIP    # late terms behind the chain, not in the row
+                late = [[] for _ in range(cnt)]
                 if (flags >> lsch.F_NLATE_SHIFT) & 3:            # late terms: computed by the folding lane itself
                     nl = rows(5)
                     for q in range(cnt):
                         for t in range(nl[q]):                  # a * (b * c); c = the slot holding 1.0 for a plain product
                             pos, wa, wb, wc = (rows(6 + 4 * t + j)[q] for j in range(4))
                             with np.errstate(all="ignore"):
-                                m[base[q] + pos] = m[wa >> 1] * (m[wb >> 1] * m[wc >> 1])
+                                if llast:
+                                    late[q].append(m[wa >> 1] * (m[wb >> 1] * m[wc >> 1]))
+                                else:
+                                    m[base[q] + pos] = m[wa >> 1] * (m[wb >> 1] * m[wc >> 1])
                 for q in range(cnt):
                     # a padded row (ordered sums) is added up to the next multiple of 8: the pads must hold -0.0
                     nrow = -(-ln[q] // 8) * 8 if flags & lsch.F_PADDED else ln[q]
-                    res.append(_fold(op, aux, [m[base[q] + k] for k in range(nrow)], m[h0[q] >> 1], m[h1[q] >> 1]))
+                    res.append(_fold(op, aux & ~lsch.LATE_LAST if llast else aux,
+                                     [m[base[q] + k] for k in range(nrow)] + late[q], m[h0[q] >> 1], m[h1[q] >> 1]))
             else:
                 ln = rows(1)
                 for q in range(cnt):
