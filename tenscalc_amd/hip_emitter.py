@@ -1519,6 +1519,57 @@ def emit_class(spec, fp_contract="fast", block=64, stats=False, roll=True, min_w
     return "".join(w), L
 
 
+def _ldsc_splittable(r, two_phase=True, split_hbm=True):
+    """tc_ldsm.hip.inc, "two-phase records": SHORT records (those with operands / results in HBM too: the loads of a step
+    are then in flight together); LDS-only ordered sums of up to TCL_FOLD_ALL (48) staged terms whose late terms, if any,
+    follow the chain.  r = one row of the header table."""
+    from . import instructions as I
+    from . import ldsm_schedule as lsch
+    kind, op, fl = int(r[0]) >> 8, int(r[0]) & 255, int(r[5])
+    if not two_phase:
+        return False
+    if kind == 1:
+        return split_hbm or not (fl & 3)
+    if fl & 3:
+        return False
+    dots = (I.I_minus_dot, I.I_minus_dot_div, I.I_plus_minus_dot, I.I_plus_minus_dot_div)
+    if kind == 3 and int(r[1]) <= 48 and (op in dots or op == lsch.F_SUM):
+        nlm = (fl >> lsch.F_NLATE_SHIFT) & 3
+        return nlm == 0 or (op in dots and bool(int(r[2]) & lsch.LATE_LAST))
+    return False
+
+
+def _ldsc_byte_words(cs, two_phase=True, split_hbm=True):
+    """the code array of a compiled class: in the body of every LDS-only record that runs in two phases, operand words
+    a*2+sign become a*8+sign and result / row addresses a become a*8 -- LDS BYTE addresses (the class has no static LDS:
+    its dynamic LDS starts at 0), one `v_and` per operand instead of shift, mask and add of the base.  The stream itself
+    (cs["words"]: what the CPU model and validate() read) is untouched."""
+    import numpy as np
+    from . import ldsm_schedule as lsch
+    words = np.asarray(cs["words"], dtype=np.int64).copy()
+    hd = np.asarray(cs["headers"], dtype=np.int64).reshape(-1, 8)
+    for r in hd:
+        kind, n, off, fl, cn = int(r[0]) >> 8, int(r[1]), int(r[4]), int(r[5]), int(r[6])
+        if kind not in (1, 3) or (fl & 3) or not _ldsc_splittable(r, two_phase, split_hbm):
+            continue
+        nlm = (fl >> lsch.F_NLATE_SHIFT) & 3 if kind == 3 else 0
+        na = 1 + n if kind == 1 else (12 if nlm else 5)
+        S = -(-na // 4) * 4
+        b = words[off:off + S * cn].reshape(cn, S)
+        opw = lambda c_: ((b[:, c_] >> 1) << 3) | (b[:, c_] & 1)        # noqa: E731
+        b[:, 0] = b[:, 0] << 3
+        if kind == 1:
+            for j in range(1, 1 + n):
+                b[:, j] = opw(j)
+        else:                 # dest, len, head0, head1, base (, nlate | positions, a0, b0, c0, a1, b1, c1)
+            b[:, 2], b[:, 3] = opw(2), opw(3)
+            b[:, 4] = b[:, 4] << 3
+            if nlm:
+                for j in range(6, 12):
+                    b[:, j] = opw(j)
+    return [int(x) for x in words]
+
+
 def _ldsc_functions(cs, W, chunk=96, depth=8, trace=False):
     from . import instructions as I
     from . import ldsm_schedule as lsch
@@ -1574,21 +1625,7 @@ def _ldsc_functions(cs, W, chunk=96, depth=8, trace=False):
                         steps.append(cur)
                     cur.append(h)
 
-                def splittable(h):
-                    """tc_ldsm.hip.inc, "two-phase records": LDS-only SHORT records; LDS-only ordered sums of up to
-                    TCL_FOLD_ALL (48) staged terms whose late terms, if any, follow the chain"""
-                    kind, op, fl = int(hd[h, 0]) >> 8, int(hd[h, 0]) & 255, int(hd[h, 5])
-                    if not two_phase:
-                        return False
-                    if kind == 1:
-                        return split_hbm or not (fl & 3)     # also with operands / results in HBM: the loads of a step together
-                    if fl & 3:
-                        return False
-                    dots = (I.I_minus_dot, I.I_minus_dot_div, I.I_plus_minus_dot, I.I_plus_minus_dot_div)
-                    if kind == 3 and int(hd[h, 1]) <= 48 and (op in dots or op == lsch.F_SUM):
-                        nlm = (fl >> lsch.F_NLATE_SHIFT) & 3
-                        return nlm == 0 or (op in dots and bool(int(hd[h, 2]) & lsch.LATE_LAST))
-                    return False
+                splittable = lambda h: _ldsc_splittable(hd[h], two_phase, split_hbm)      # noqa: E731
                 for st in steps:
                     h0_ = st[0]
                     if (int(hd[h0_, 0]) >> 8) == 2:                              # a barrier record of its own
@@ -1703,7 +1740,11 @@ def emit_class_ldsm(spec, waves=4, stats=False, lds_slots=20000, fuse_chain=True
              "static __device__ __forceinline__ double tc_max(double a, double x) { return (a < x) ? x : a; }\n"
              "static __device__ __forceinline__ double tc_clp(double a, double x, double dx) {\n"
              "  if (dx < 0) { const double t = -x / dx; if (a > t) a = t; }\n  return a;\n}\n\n")
-    arr = lsch.as_array(cs["words"] + [0] * 1024)    # the body prefetch reads up to 16 rows of 64 past a record
+    code_words = cs["words"]
+    if compiled and os.environ.get("TC_LDSC_BYTES", "1") != "0":
+        code_words = _ldsc_byte_words(cs, os.environ.get("TC_LDSC_TWO_PHASE", "1") != "0", os.environ.get("TC_LDSC_SPLIT_HBM", "1") != "0")
+        w.append("#define TC_LDSC_BYTES 1\n")
+    arr = lsch.as_array(code_words + [0] * 1024)    # the body prefetch reads up to 16 rows of 64 past a record
     w.append(f"// the tape as data: {arr.size} body words, {len(cs['headers']) // 8} record headers\n"
              "static __device__ const int tc_code[] __attribute__((aligned(64))) = {\n")
     for k0 in range(0, arr.size, 32):
@@ -1810,6 +1851,8 @@ def emit_class_ldsm(spec, waves=4, stats=False, lds_slots=20000, fuse_chain=True
              "  c.lane = (int)(threadIdx.x & 63);\n  for (int k = 0; k < TC_NSTW; k++) c.st[k] = 0;\n"
              "#ifdef TC_STATS\n  c.nMinF = 0;\n  for (int k = 0; k < TC_NGROUPS; k++) { c.cyc[k] = 0; c.cnt[k] = 0; }\n"
              "  for (int k = 0; k < 8; k++) c.ph[k] = 0;\n  const long long tstart_ = clock64();\n  c.tph = tstart_;\n#endif\n"
+             "#ifdef TC_LDSC_BYTES\n  // two-phase records address the LDS by byte offsets from 0: the class has no static LDS\n"
+             "  if ((unsigned)(size_t)c.m != 0u) { if (threadIdx.x == 0) { status[tid] = 0x7fffffff; iter[tid] = -1; } return; }\n#endif\n"
              "  for (int k = threadIdx.x; k < TC_NCONST; k += TC_BLOCK) c.m[tc_const_addr[k]] = tc_consts[k];\n"
              "  if (threadIdx.x == 0) c.m[0] = 0.0;\n"
              + ("  if (threadIdx.x == 0) { __attribute__((address_space(3))) long long *q_ = (__attribute__((address_space(3))) long long *)&c.m[TCC_CUR_SLOT - 2]; "
@@ -2000,7 +2043,7 @@ def build_class(spec, fp_contract="fast", arch="gfx950", opt="-O3", block=64, fo
     kq.update(repr((cls, sorted(spec.defines.items()), [(n, tuple(sz)) for n, sz in spec.outputs], fp_contract, arch, opt, block,
                     stats, tag, tuple(extra_flags), roll, min_waves, lanes, recip, fast_div, inline_max, reg_budget, scratch,
                     body, waves, fuse, static_clean, forward, rcache, lds_state, share, branch_free_tails, exact, stg_blocks,
-                    lds_slots, ilp, fw_window, sched_every, tuple(try_flags), refresh_outputs, compiled, os.environ.get("TC_LDS_PAD_SLOTS", ""), os.environ.get("TC_STG_BATCH", ""), os.environ.get("TC_LDSM_FUSE", ""), os.environ.get("TC_LDSC_DEPTH", ""), os.environ.get("TC_LDSM_PACK_LOCALS", ""), os.environ.get("TC_LDSM_ROW_SKEW", ""), os.environ.get("TC_LDSM_LATE_LAST", ""), os.environ.get("TC_LDSC_TWO_PHASE", ""), os.environ.get("TC_LDSC_SPLIT_HBM", ""), os.environ.get("TC_LDSC_SCHEDB", ""),
+                    lds_slots, ilp, fw_window, sched_every, tuple(try_flags), refresh_outputs, compiled, os.environ.get("TC_LDS_PAD_SLOTS", ""), os.environ.get("TC_STG_BATCH", ""), os.environ.get("TC_LDSM_FUSE", ""), os.environ.get("TC_LDSC_DEPTH", ""), os.environ.get("TC_LDSM_PACK_LOCALS", ""), os.environ.get("TC_LDSM_ROW_SKEW", ""), os.environ.get("TC_LDSM_LATE_LAST", ""), os.environ.get("TC_LDSC_TWO_PHASE", ""), os.environ.get("TC_LDSC_SPLIT_HBM", ""), os.environ.get("TC_LDSC_SCHEDB", ""), os.environ.get("TC_LDSC_BYTES", ""),
                     os.environ.get("TC_SWEEP_UNROLL", ""))).encode())
     for f_ in sorted(os.listdir(HERE)):
         if f_.endswith(".py"):
