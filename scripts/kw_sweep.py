@@ -32,6 +32,9 @@ def build(st):
         if k == "E":          # E=NAME:VALUE -> environment variable of the emitter (hashed into the build key)
             os.environ[v.split(":")[0]] = v.split(":")[1]
             continue
+        if k == "F":          # F=-amdgpu-sched-strategy:max-ilp -> -mllvm -amdgpu-sched-strategy=max-ilp
+            kw["extra_flags"] = tuple(kw.get("extra_flags", ())) + ("-mllvm", v.replace(":", "="))
+            continue
         if k == "D":          # D=NAME:VALUE -> -DNAME=VALUE (diagnostic builds, e.g. D=TCL_DUP_CHAIN:2)
             kw["extra_flags"] = tuple(kw.get("extra_flags", ())) + ("-D" + v.replace(":", "="),)
             continue

@@ -1574,6 +1574,7 @@ def _ldsc_functions(cs, W, chunk=96, depth=8, trace=False):
     from . import instructions as I
     from . import ldsm_schedule as lsch
     two_phase = os.environ.get("TC_LDSC_TWO_PHASE", "1") != "0"
+    wpe = "__attribute__((amdgpu_waves_per_eu(1, 1))) " if os.environ.get("TC_LDSC_WPE", "0") != "0" else ""
     split_hbm = os.environ.get("TC_LDSC_SPLIT_HBM", "1") != "0"     # tuning aids (hashed into the build key)
     sched_b = os.environ.get("TC_LDSC_SCHEDB", "0") != "0"          # measured: 202.3 ms with, 200.9 without (quadcopter, 512)
     """body="ldsm", compiled=True: the record stream printed as code.  Per record range (a dependency group or a copy
@@ -1601,7 +1602,7 @@ def _ldsc_functions(cs, W, chunk=96, depth=8, trace=False):
                 part = recs[c0:c0 + chunk]
                 nm = f"tcc_r{rid}_w{k}_{c0 // chunk}"
                 names.append(nm)
-                body = [f"static __device__ __noinline__ void {nm}(tc_lds lds, tc_gmem gm, const int lane) {{\n"
+                body = [f"static __device__ __noinline__ {wpe}void {nm}(tc_lds lds, tc_gmem gm, const int lane) {{\n"
                         "  tc_gcode_p code = (tc_gcode_p)tc_code;\n"
                         "  int " + ", ".join(f"R{q}[TCL_NR]" for q in range(depth)) + ";\n"]
                 real = [h for h in part if (int(hd[h, 0]) >> 8) != 2]        # records with a body (not barriers)
@@ -2043,7 +2044,7 @@ def build_class(spec, fp_contract="fast", arch="gfx950", opt="-O3", block=64, fo
     kq.update(repr((cls, sorted(spec.defines.items()), [(n, tuple(sz)) for n, sz in spec.outputs], fp_contract, arch, opt, block,
                     stats, tag, tuple(extra_flags), roll, min_waves, lanes, recip, fast_div, inline_max, reg_budget, scratch,
                     body, waves, fuse, static_clean, forward, rcache, lds_state, share, branch_free_tails, exact, stg_blocks,
-                    lds_slots, ilp, fw_window, sched_every, tuple(try_flags), refresh_outputs, compiled, os.environ.get("TC_LDS_PAD_SLOTS", ""), os.environ.get("TC_STG_BATCH", ""), os.environ.get("TC_LDSM_FUSE", ""), os.environ.get("TC_LDSC_DEPTH", ""), os.environ.get("TC_LDSM_PACK_LOCALS", ""), os.environ.get("TC_LDSM_ROW_SKEW", ""), os.environ.get("TC_LDSM_LATE_LAST", ""), os.environ.get("TC_LDSC_TWO_PHASE", ""), os.environ.get("TC_LDSC_SPLIT_HBM", ""), os.environ.get("TC_LDSC_SCHEDB", ""), os.environ.get("TC_LDSC_BYTES", ""),
+                    lds_slots, ilp, fw_window, sched_every, tuple(try_flags), refresh_outputs, compiled, os.environ.get("TC_LDS_PAD_SLOTS", ""), os.environ.get("TC_STG_BATCH", ""), os.environ.get("TC_LDSM_FUSE", ""), os.environ.get("TC_LDSC_DEPTH", ""), os.environ.get("TC_LDSM_PACK_LOCALS", ""), os.environ.get("TC_LDSM_ROW_SKEW", ""), os.environ.get("TC_LDSM_LATE_LAST", ""), os.environ.get("TC_LDSC_TWO_PHASE", ""), os.environ.get("TC_LDSC_SPLIT_HBM", ""), os.environ.get("TC_LDSC_SCHEDB", ""), os.environ.get("TC_LDSC_BYTES", ""), os.environ.get("TC_LDSC_WPE", ""),
                     os.environ.get("TC_SWEEP_UNROLL", ""))).encode())
     for f_ in sorted(os.listdir(HERE)):
         if f_.endswith(".py"):
