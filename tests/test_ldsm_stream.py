@@ -7,6 +7,8 @@ group-local scratch region), the levels, the record packing, the split of long i
 + an ordered fold, sign bits, heads of the dot opcodes.  Storage is SHARED by life time, so the model has to
 call the entry points in the order the solver does (csrc/ipm_newton.hip.inc); the device walk itself is checked
 against the oracle in tests/test_gpu_interp.py."""
+import os
+
 import numpy as np
 import pytest
 
@@ -364,3 +366,73 @@ def test_ldsm_stream_schedule_options_agree(native_built, tape_oracle, tmp_path,
     hd = np.asarray(cs["headers"]).reshape(-1, 8)
     steps = int(((hd[:, 0] >> 8) == lsch.K_BARRIER).sum() + (((hd[:, 0] >> 8) != lsch.K_BARRIER) & ((hd[:, 5] & lsch.F_BARRIER_AFTER) > 0)).sum())
     print(kw, "records", len(hd), "barriers (all waves)", steps)
+
+
+def test_late_terms_behind_the_chain_are_used_and_can_be_switched_off(native_built, tape_oracle, tmp_path, monkeypatch):
+    """ldsm_schedule.LATE_LAST: rows whose late terms are their last terms keep -0.0 in the late slots and add the late
+    products behind the chain -- the model above executes exactly that against the oracle; TC_LDSM_LATE_LAST=0 gives
+    the round-3 stream (late terms written into the row), same values"""
+    from tenscalc_amd.problems.mpc_dcmotor import SOLVE_ARGS, dcmotor_data, mpc_dcmotor
+    spec = mpc_dcmotor(folder=str(tmp_path))
+    cs = _check(spec, dcmotor_data(9), tape_oracle, SOLVE_ARGS, W=4, fuse=True)
+    hd = np.asarray(cs["headers"], dtype=np.int64).reshape(-1, 8)
+    f = hd[(hd[:, 0] >> 8) == lsch.K_FOLD]
+    late = ((f[:, 5] >> lsch.F_NLATE_SHIFT) & 3) > 0
+    assert (late & ((f[:, 2] & lsch.LATE_LAST) != 0)).sum() > 50
+    for h in f[late & ((f[:, 2] & lsch.LATE_LAST) != 0)]:       # such a record never writes into its rows
+        rd, wr = lsch.record_accesses(cs["words"], h)
+        body = lsch.record_body(cs["words"], h)
+        assert wr == set(int(x) for x in body[0][:int(h[3])])
+    monkeypatch.setenv("TC_LDSM_LATE_LAST", "0")
+    cs0 = _check(spec, dcmotor_data(9), tape_oracle, SOLVE_ARGS, W=4, fuse=True)
+    f0 = np.asarray(cs0["headers"], dtype=np.int64).reshape(-1, 8)
+    assert not ((f0[(f0[:, 0] >> 8) == lsch.K_FOLD][:, 2] & lsch.LATE_LAST) != 0).any()
+
+
+def test_byte_address_words_of_the_compiled_walk_decode_to_the_stream(native_built, tmp_path):
+    """hip_emitter._ldsc_byte_words rewrites the body words of LDS-only two-phase records (a*2+sign -> a*8+sign, result
+    and row addresses a -> a*8) and nothing else: decoding gives the stream back, word for word"""
+    from tenscalc_amd import hip_emitter as he
+    from tenscalc_amd.problems.mpc_dcmotor import mpc_dcmotor
+    spec = mpc_dcmotor(folder=str(tmp_path))
+    T = spec.tape.merged(lsch.fusion_sets(spec.tape))
+    cs = lsch.class_stream(T, spec.classname, spec.defines, W=1)
+    bw = np.asarray(he._ldsc_byte_words(cs), dtype=np.int64)
+    w = np.asarray(cs["words"], dtype=np.int64)
+    hd = np.asarray(cs["headers"], dtype=np.int64).reshape(-1, 8)
+    changed = np.zeros(len(w), dtype=bool)
+    nsplit = 0
+    for r in hd:
+        kind, n, off, fl, cn = int(r[0]) >> 8, int(r[1]), int(r[4]), int(r[5]), int(r[6])
+        if kind not in (1, 3) or (fl & 3) or not he._ldsc_splittable(r):
+            continue
+        nsplit += 1
+        nlm = (fl >> lsch.F_NLATE_SHIFT) & 3 if kind == 3 else 0
+        na = 1 + n if kind == 1 else (12 if nlm else 5)
+        S = -(-na // 4) * 4
+        b, o = bw[off:off + S * cn].reshape(cn, S), w[off:off + S * cn].reshape(cn, S)
+        ops = list(range(1, 1 + n)) if kind == 1 else [2, 3] + (list(range(6, 12)) if nlm else [])
+        addr = [0] if kind == 1 else [0, 4]
+        for c_ in ops:
+            assert np.array_equal(((b[:, c_] >> 3) << 1) | (b[:, c_] & 1), o[:, c_]) and not (b[:, c_] & 6).any()
+        for c_ in addr:
+            assert np.array_equal(b[:, c_] >> 3, o[:, c_]) and not (b[:, c_] & 7).any()
+        rest = [c_ for c_ in range(S) if c_ not in ops + addr]
+        assert np.array_equal(b[:, rest], o[:, rest])
+        changed[off:off + S * cn] = True
+    assert nsplit > 100 and np.array_equal(bw[~changed], w[~changed])
+    assert bw.max() < 2 ** 31
+
+
+def test_class_digest_covers_exactly_the_files_a_class_includes():
+    """hip_emitter._deps_of: the include closure of a class source -- an edit of csrc/tc_ldsm.hip.inc rebuilds the LDS
+    machine's classes and nobody else's"""
+    from tenscalc_amd import hip_emitter as he
+    names = lambda src: {os.path.basename(p) for p in he._deps_of(src)}      # noqa: E731
+    code = '#include "tc_wave.hip.inc"\n#include "tc_pow.hip.inc"\n#include "ipm_newton.hip.inc"\n#include "tc_runtime.hip.inc"\n'
+    d = names(code)
+    assert {"tc_wave.hip.inc", "tc_pow.hip.inc", "tc_glibcpow.hip.inc", "tc_glibcpow_tables.inc", "tc_crmath.hip.inc",
+            "ipm_newton.hip.inc", "tc_runtime.hip.inc", "tenscalc_hip.h"} <= d
+    assert "tc_ldsm.hip.inc" not in d and "tc_interp.hip.inc" not in d
+    d = names('#include "tc_ldsm.hip.inc"\n')
+    assert {"tc_ldsm.hip.inc", "tc_interp.hip.inc", "tc_pow.hip.inc"} <= d and "tc_wave.hip.inc" not in d
