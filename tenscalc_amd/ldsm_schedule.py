@@ -516,6 +516,7 @@ def build_stream(T, addr, nLds, W=1, stage_base=None, nStage=0, hoist=True, pads
         return (up8(n_) if s_["fop"] in _PADDED_FOPS else n_) + SKEW
     SKEW = int(os.environ.get("TC_LDSM_ROW_SKEW", "2"))
     LATE_LAST_ON = os.environ.get("TC_LDSM_LATE_LAST", "1") != "0"
+    PADS_AS_PRODUCTS = os.environ.get("TC_LDSM_PAD_PRODUCTS", "1") != "0"
     # staging area = two alternating halves for terms computed one step ahead + the classic region, which must hold
     # the longest staged instruction of the class
     longest = 0
@@ -694,18 +695,29 @@ def build_stream(T, addr, nLds, W=1, stage_base=None, nStage=0, hoist=True, pads
                 return (OP_PROD3, 3, 0) if len(tw) == 3 and s_["tn"] == 2 else (I.I_sumprod, s_["tn"], s_["tn"])
             return (s_["top"], s_["tn"], 0)
 
-        def pad_row(terms, fop, base, n_):
+        def pad_row(terms, fop, base, n_, like=None):
             """the operation's identity (-0.0 for sums, +inf for minima, -inf for maxima) into the slots between the
-            end of a row of n_ terms and the next multiple of 8"""
+            end of a row of n_ terms and the next multiple of 8.  like = the key of the row's own two-factor products:
+            the pad is then written as identity * 1.0 by the record that computes those products (one record less in
+            nearly every step of a factorisation; -0.0 * 1.0 is -0.0, inf * 1.0 is inf)"""
             if fop in _PADDED_FOPS:
                 for q in range(n_, up8(n_)):
-                    terms.setdefault((OP_COPY, 1, 0), []).append((base + q, [pads[_PADDED_FOPS[fop]] * 2]))
+                    pw = pads[_PADDED_FOPS[fop]] * 2
+                    if like is not None and PADS_AS_PRODUCTS:
+                        terms.setdefault(like, []).append((base + q, [pw, one * 2]))
+                    else:
+                        terms.setdefault((OP_COPY, 1, 0), []).append((base + q, [pw]))
 
         def add_pads(terms, s_, base, hoisted=False):
             n_ = len(s_["terms"])
             if hoisted and late_last(s_):
                 n_ -= sum(s_["late"])       # the late slots are never written: the identity from the first of them on
-            pad_row(terms, s_["fop"], base, n_)
+            like = None
+            if one is not None and s_["top"] == "prod" and s_["tn"] == 2 and not s_.get("split"):
+                plain = [tw for q, tw in enumerate(s_["terms"]) if len(tw) == 2 and not (hoisted and s_["late"][q])]
+                if plain:                    # the row has plain products staged in this very step
+                    like = term_key(s_, plain[0])
+            pad_row(terms, s_["fop"], base, n_, like)
         toggle = 0               # which staging half the next hoisted level's early terms go to
         for idx, lv in enumerate(info):
             recs = cut(lv["short"], K_SHORT, lambda nn, it: nn + 6) + cut(lv["long_"], K_LONG, lambda nn, it: len(it[1]) + 8)
