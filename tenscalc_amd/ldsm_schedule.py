@@ -517,6 +517,7 @@ def build_stream(T, addr, nLds, W=1, stage_base=None, nStage=0, hoist=True, pads
     SKEW = int(os.environ.get("TC_LDSM_ROW_SKEW", "2"))
     LATE_LAST_ON = os.environ.get("TC_LDSM_LATE_LAST", "1") != "0"
     PADS_AS_PRODUCTS = os.environ.get("TC_LDSM_PAD_PRODUCTS", "1") != "0"
+    MERGE_PRODUCTS = os.environ.get("TC_LDSM_MERGE_PRODUCTS", "1") != "0"
     # staging area = two alternating halves for terms computed one step ahead + the classic region, which must hold
     # the longest staged instruction of the class
     longest = 0
@@ -565,6 +566,21 @@ def build_stream(T, addr, nLds, W=1, stage_base=None, nStage=0, hoist=True, pads
         # mpc_quadcopter (scripts/level_trace.py) puts a step of one short record at ~600 cycles and a fold of 24 terms
         # with late terms at ~1 300 -- the wavefront that folds should get nothing else until the others hold three shorts
         FOLD_COST = lambda nn, it: it[1][0] + 30       # noqa: E731
+
+        def merge_products(terms):
+            """plain products a*b that do not fill their last record ride in the record of the nested ones, as a*(b*1.0),
+            when that saves a record (x * 1.0 is x)"""
+            k2, k3 = (I.I_sumprod, 2, 2), (OP_PROD3, 3, 0)
+            if MERGE_PRODUCTS and one is not None and k2 in terms and k3 in terms:
+                n2, n3 = len(terms[k2]), len(terms[k3])
+                r2 = n2 % LANES
+                if r2 and -(-n2 // LANES) + -(-n3 // LANES) > -(-(n2 - r2) // LANES) + -(-(n3 + r2) // LANES):
+                    moved = terms[k2][n2 - r2:]
+                    terms[k2] = terms[k2][:n2 - r2]
+                    if not terms[k2]:
+                        del terms[k2]
+                    terms[k3] = terms[k3] + [(d, list(a) + [one * 2]) for d, a in moved]
+            return terms
 
         def cut(groups_, kind, cost):
             recs = []
@@ -736,7 +752,7 @@ def build_stream(T, addr, nLds, W=1, stage_base=None, nStage=0, hoist=True, pads
                     used += rowlen(s_)             # the late terms keep their slot in the row: the folding lane fills it
                 if used > half:
                     raise AssertionError("staging half overflow")
-                ahead_next = cut(terms, K_SHORT, lambda nn, it: nn + 6)
+                ahead_next = cut(merge_products(terms), K_SHORT, lambda nn, it: nn + 6)
             staged = lv["staged"]
             if lv["hoist"]:
                 folds = {}
@@ -783,7 +799,7 @@ def build_stream(T, addr, nLds, W=1, stage_base=None, nStage=0, hoist=True, pads
                             folds.setdefault((s_["fop"], 0, s_["aux"]), []).append(fold_item(s_, base, False))
                         used += rowlen(s_)
                         k0 += 1
-                    emit(recs + cut(terms, K_SHORT, lambda nn, it: nn + 6))
+                    emit(recs + cut(merge_products(terms), K_SHORT, lambda nn, it: nn + 6))
                     recs = []
                     for key, items in folds.items():
                         folds[key] = sorted(items, key=lambda it: -it[1][0])
