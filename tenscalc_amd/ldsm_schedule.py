@@ -582,6 +582,28 @@ def build_stream(T, addr, nLds, W=1, stage_base=None, nStage=0, hoist=True, pads
                     terms[k3] = terms[k3] + [(d, list(a) + [one * 2]) for d, a in moved]
             return terms
 
+        def merge_short_dots(short):
+            """short dot products of one opcode but different lengths share a record when that saves one: the shorter
+            ones are padded with products (-0.0) * 1.0 behind their last term -- x + (-0.0) is x"""
+            if not (MERGE_PRODUCTS and one is not None and pads is not None):
+                return short
+            for op in _DOTS:
+                keys = [k_ for k_ in short if k_[0] == op]
+                if len(keys) < 2:
+                    continue
+                total = sum(len(short[k_]) for k_ in keys)
+                if -(-total // LANES) >= sum(-(-len(short[k_]) // LANES) for k_ in keys):
+                    continue
+                nmax_ = max(k_[1] for k_ in keys)
+                if any((nmax_ - k_[1]) % 2 for k_ in keys):
+                    continue
+                items = []
+                for k_ in sorted(keys):
+                    for d, a in short.pop(k_):
+                        items.append((d, list(a) + [pads[0] * 2, one * 2] * ((nmax_ - k_[1]) // 2)))
+                short[(op, nmax_, 0)] = items
+            return short
+
         def cut(groups_, kind, cost):
             recs = []
             for (op, nn, aux), items in sorted(groups_.items()):
@@ -736,7 +758,7 @@ def build_stream(T, addr, nLds, W=1, stage_base=None, nStage=0, hoist=True, pads
             pad_row(terms, s_["fop"], base, n_, like)
         toggle = 0               # which staging half the next hoisted level's early terms go to
         for idx, lv in enumerate(info):
-            recs = cut(lv["short"], K_SHORT, lambda nn, it: nn + 6) + cut(lv["long_"], K_LONG, lambda nn, it: len(it[1]) + 8)
+            recs = cut(merge_short_dots(lv["short"]), K_SHORT, lambda nn, it: nn + 6) + cut(lv["long_"], K_LONG, lambda nn, it: len(it[1]) + 8)
             nxt = info[idx + 1] if idx + 1 < len(info) else None
             ahead_next = []
             if nxt is not None and nxt["hoist"]:
