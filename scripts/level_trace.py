@@ -29,10 +29,7 @@ kw["tag"] = variant + "_levels"
 so = spec.build(**kw)
 meta = os.path.splitext(so)[0] + ".levels.npz"
 if mode == "build":
-    T = spec.tape
-    fs = lsch.fusion_sets(T)
-    if fs:
-        T = T.merged(fs)
+    T = lsch.fused_tape(spec.tape, spec.defines)
     cs = lsch.class_stream(T, spec.classname, spec.defines, W=int(kw["waves"]), lds_slots=kw.get("lds_slots", 20000))
     np.savez(meta, headers=np.asarray(cs["headers"], dtype=np.int64).reshape(-1, 8), table=np.asarray(cs["table"], dtype=np.int64))
     print(so, meta)

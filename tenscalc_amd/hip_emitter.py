@@ -1698,12 +1698,11 @@ def emit_class_ldsm(spec, waves=4, stats=False, lds_slots=20000, fuse_chain=True
         raise NotImplementedError("body='ldsm' packs the state by life times derived from the call structure of "
                                   "ipmPD_CSsolver; equilibrium classes: lanes=1 printed code or body='interp'")
     T = spec.tape
-    if fuse_chain and os.environ.get("TC_LDSM_FUSE", "1") != "0":
-        # the factorisation and the substitutions that read it as ONE level schedule (ldsm_schedule.fusion_sets): the
-        # class walks a tape whose dependency groups are coarser than the reference's; values are unchanged
-        fs = lsch.fusion_sets(T)
-        if fs:
-            T = T.merged(fs)
+    if fuse_chain:
+        # the class walks a tape whose dependency groups are coarser than the reference's (ldsm_schedule.fused_tape: the
+        # factorisation and the substitutions that read it as ONE level schedule; the groups one solve cannot tell apart
+        # as one group); values are unchanged
+        T = lsch.fused_tape(T, spec.defines)
     cls = spec.classname
     W = int(waves)
     cs = lsch.class_stream(T, cls, spec.defines, W=W, lds_slots=lds_slots)
@@ -2044,7 +2043,7 @@ def build_class(spec, fp_contract="fast", arch="gfx950", opt="-O3", block=64, fo
     kq.update(repr((cls, sorted(spec.defines.items()), [(n, tuple(sz)) for n, sz in spec.outputs], fp_contract, arch, opt, block,
                     stats, tag, tuple(extra_flags), roll, min_waves, lanes, recip, fast_div, inline_max, reg_budget, scratch,
                     body, waves, fuse, static_clean, forward, rcache, lds_state, share, branch_free_tails, exact, stg_blocks,
-                    lds_slots, ilp, fw_window, sched_every, tuple(try_flags), refresh_outputs, compiled, os.environ.get("TC_LDS_PAD_SLOTS", ""), os.environ.get("TC_STG_BATCH", ""), os.environ.get("TC_LDSM_FUSE", ""), os.environ.get("TC_LDSC_DEPTH", ""), os.environ.get("TC_LDSM_PACK_LOCALS", ""), os.environ.get("TC_LDSM_ROW_SKEW", ""), os.environ.get("TC_LDSM_LATE_LAST", ""), os.environ.get("TC_LDSM_PAD_PRODUCTS", ""), os.environ.get("TC_LDSM_MERGE_PRODUCTS", ""), os.environ.get("TC_LDSM_COLD_RANK", ""), os.environ.get("TC_LDSC_TWO_PHASE", ""), os.environ.get("TC_LDSC_SPLIT_HBM", ""), os.environ.get("TC_LDSC_SCHEDB", ""), os.environ.get("TC_LDSC_BYTES", ""), os.environ.get("TC_LDSC_WPE", ""),
+                    lds_slots, ilp, fw_window, sched_every, tuple(try_flags), refresh_outputs, compiled, os.environ.get("TC_LDS_PAD_SLOTS", ""), os.environ.get("TC_STG_BATCH", ""), os.environ.get("TC_LDSM_FUSE", ""), os.environ.get("TC_LDSM_LOOP_MERGE", ""), os.environ.get("TC_LDSC_DEPTH", ""), os.environ.get("TC_LDSM_PACK_LOCALS", ""), os.environ.get("TC_LDSM_ROW_SKEW", ""), os.environ.get("TC_LDSM_LATE_LAST", ""), os.environ.get("TC_LDSM_PAD_PRODUCTS", ""), os.environ.get("TC_LDSM_MERGE_PRODUCTS", ""), os.environ.get("TC_LDSM_COLD_RANK", ""), os.environ.get("TC_LDSC_TWO_PHASE", ""), os.environ.get("TC_LDSC_SPLIT_HBM", ""), os.environ.get("TC_LDSC_SCHEDB", ""), os.environ.get("TC_LDSC_BYTES", ""), os.environ.get("TC_LDSC_WPE", ""),
                     os.environ.get("TC_SWEEP_UNROLL", ""))).encode())
     for f_ in sorted(os.listdir(HERE)):
         if f_.endswith(".py"):

@@ -191,6 +191,117 @@ def fusion_sets(T, min_gain=32):
     return out
 
 
+def loop_classes(T, defines):
+    """Sets of dependency groups that the Newton loop evaluates at exactly the same call sites and invalidates with the
+    same entry points (loop_schedule.timeline: positions where a group may be evaluated; parameter sets are not part of a
+    solve and do not count).  The reference keeps them apart because some OTHER program could call their entry points
+    separately; inside one solve kernel they are one group -- one evaluation, one level schedule in which independent
+    members overlap, no hand-over between them (a group transition costs the compiled walk ~1 300 cycles: return, flag
+    test, workgroup barrier, dispatch, the first records' body words).  A set must be convex (no outside group on a path
+    between two members) and the sets together must leave the group graph acyclic; members are dropped until they do."""
+    from .loop_schedule import timeline
+    try:
+        E = timeline(T, defines)["E"]
+    except Exception:           # a loop this analysis does not know (equilibrium solvers): no merging
+        return []
+    nG = T.nGroups
+    opl, ost = T.ops.tolist(), T.opStart.tolist()
+    grp = T.group
+    preds = [set() for _ in range(nG + 1)]
+    for i in range(1, T.n + 1):
+        gi = int(grp[i])
+        if gi and T.used[i]:
+            for j in opl[ost[i - 1]:ost[i]]:
+                gj = int(grp[j])
+                if gj and gj != gi:
+                    preds[gi].add(gj)
+    anc = [set() for _ in range(nG + 1)]
+    for g in range(1, nG + 1):
+        for p_ in preds[g]:
+            anc[g] |= anc[p_] | {p_}
+    ext = {e["name"] for e in T.sets if e["external"]}
+    inval = [set() for _ in range(nG + 1)]
+    for e in list(T.sets) + list(T.copies):
+        if e["name"] not in ext:
+            for c_ in e["children"]:
+                inval[c_].add(e["name"])
+    # ... and needed by the same entry points: the initialisation sequence is ONE position of the timeline, but a group
+    # that scaleIneq__ needs must not be evaluated with one that initDualEqX__ needs -- its inputs are not there yet
+    # (the CPU model of tests/test_ldsm_stream.py caught exactly that on mpc_dcmotor)
+    needed = [set() for _ in range(nG + 1)]
+    for e in list(T.gets) + list(T.copies):
+        for p_ in e["parents"]:
+            needed[p_].add(e["name"])
+    classes = {}
+    for g in range(1, nG + 1):
+        if E.get(g):
+            classes.setdefault((tuple(E[g]), tuple(sorted(needed[g])), tuple(sorted(inval[g]))), []).append(g)
+    sets = []
+    for members in classes.values():
+        # convex subsets, greedily in topological (= numerical) order
+        rest = list(members)
+        while len(rest) > 1:
+            cur = [rest[0]]
+            for g in rest[1:]:
+                between = {x for x in anc[g] if any(c_ in anc[x] for c_ in cur)} - set(cur)
+                if not between:
+                    cur.append(g)
+            if len(cur) > 1:
+                sets.append(cur)
+            rest = [g for g in rest if g not in cur]
+    # jointly acyclic: contract, Kahn; a set on a cycle loses its last member until the graph is a DAG
+    while True:
+        rep = list(range(nG + 1))
+        for S in sets:
+            for g in S:
+                rep[g] = S[0]
+        succ, indeg = {}, {}
+        nodes = {rep[g] for g in range(1, nG + 1)}
+        for g in range(1, nG + 1):
+            for p_ in preds[g]:
+                a, b = rep[p_], rep[g]
+                if a != b and b not in succ.setdefault(a, set()):
+                    succ[a].add(b)
+                    indeg[b] = indeg.get(b, 0) + 1
+        ready = [x for x in nodes if not indeg.get(x)]
+        seen = 0
+        while ready:
+            x = ready.pop()
+            seen += 1
+            for y in succ.get(x, ()):
+                indeg[y] -= 1
+                if not indeg[y]:
+                    ready.append(y)
+        if seen == len(nodes):
+            break
+        stuck = {x for x in nodes if indeg.get(x)}
+        cand = [S for S in sets if S[0] in stuck]
+        if not cand:
+            raise AssertionError("cycle among unmerged groups")
+        S = min(cand, key=len)
+        S.pop()
+        sets = [S_ for S_ in sets if len(S_) > 1]
+    return sets
+
+
+def fused_tape(T, defines):
+    """the tape the LDS machine walks: the reference's instructions and entry points, coarser dependency groups --
+    factorisation + substitutions as one level schedule (fusion_sets), then the groups one solve cannot tell apart
+    (loop_classes).  Values are unchanged.  TC_LDSM_FUSE=0 / TC_LDSM_LOOP_MERGE=0 switch the steps off."""
+    if os.environ.get("TC_LDSM_FUSE", "1") != "0":
+        fs = fusion_sets(T)
+        if fs:
+            T = T.merged(fs)
+        if os.environ.get("TC_LDSM_LOOP_MERGE", "1") != "0":
+            cs = loop_classes(T, defines)
+            if cs:
+                # (Tape.merged starts from the reference's partition: every group of THIS tape is passed, the ones that
+                # stay alone as sets of one, or the first step's merge would be undone)
+                taken = {g for S in cs for g in S}
+                T = T.merged(cs + [[g] for g in range(1, T.nGroups + 1) if g not in taken])
+    return T
+
+
 def assign_slots(T, defines, lds_slots=20000, stage=STAGE):
     """-> dict(addr=int array [n+1] (-1: no storage), nLds, nGlob, nExt, consts=[(addr, value)],
     inputs=[(first global index, numel, entry name)], dummy=LDS slot nobody reads, ...)"""
@@ -357,6 +468,15 @@ def assign_slots(T, defines, lds_slots=20000, stage=STAGE):
         else:
             hi_ = mid - 1
     hot, cold = order[:lo_], order[lo_:]
+    # ... then every later block of the ranking that still fits (merged groups export large blocks: the first one that
+    # does not fit used to end the list with 2 000 slots to spare)
+    if os.environ.get("TC_LDSM_COLD_RANK", "1") != "0":
+        for b in list(cold):
+            sz, ps = packed(hot + [b])
+            if sz <= room:
+                hot.append(b)
+                cold.remove(b)
+                best = (sz, ps)
     nHot, ps = best
     for b in hot:
         for i in blocks[b]:

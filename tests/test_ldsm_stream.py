@@ -173,7 +173,10 @@ class Machine:
 def _check(spec, data, tape_oracle, args, W=1, lds_slots=20000, stream_kw=None, fuse=False):
     T, c, D = spec.tape, spec.classname, spec.defines
     o = tape_oracle(T, c)                    # the oracle always walks the reference's partition into groups
-    if fuse:                                 # ... the machine the coarser one of hip_emitter.emit_class_ldsm(fuse_chain=True)
+    if fuse == "loop":                       # ... the machine the coarser one of hip_emitter.emit_class_ldsm(fuse_chain=True):
+        T = lsch.fused_tape(T, D)            # factor + solves, then the groups one solve cannot tell apart
+        assert T.nGroups < spec.tape.nGroups
+    elif fuse:                               # (only the first step)
         fs = lsch.fusion_sets(T, min_gain=32 if fuse is True else int(fuse))
         assert fs, "nothing to fuse on this tape"
         T = T.merged(fs)
@@ -436,3 +439,25 @@ def test_class_digest_covers_exactly_the_files_a_class_includes():
     assert "tc_ldsm.hip.inc" not in d and "tc_interp.hip.inc" not in d
     d = names('#include "tc_ldsm.hip.inc"\n')
     assert {"tc_ldsm.hip.inc", "tc_interp.hip.inc", "tc_pow.hip.inc"} <= d and "tc_wave.hip.inc" not in d
+
+
+@pytest.mark.parametrize("W", [1, 4])
+def test_ldsm_stream_groups_one_solve_cannot_tell_apart_are_merged(native_built, tape_oracle, tmp_path, W):
+    """ldsm_schedule.loop_classes: dependency groups evaluated at the same call sites of the Newton loop and invalidated
+    by the same entry points become one group (fewer hand-overs, joint level schedule); the sets are convex and leave the
+    group graph acyclic; every get still reproduces the oracle, which walks the reference's partition"""
+    from tenscalc_amd.problems.mpc_dcmotor import SOLVE_ARGS, dcmotor_data, mpc_dcmotor
+    spec = mpc_dcmotor(folder=str(tmp_path))
+    T1 = spec.tape.merged(lsch.fusion_sets(spec.tape))
+    cl = lsch.loop_classes(T1, spec.defines)
+    assert cl and all(len(S) > 1 for S in cl) and len({g for S in cl for g in S}) == sum(len(S) for S in cl)
+    T2 = lsch.fused_tape(spec.tape, spec.defines)                       # (Tape.merged refuses cycles)
+    assert T2.nGroups == T1.nGroups - sum(len(S) - 1 for S in cl) < T1.nGroups * 0.7
+    assert max(len(m_) for m_ in T2.groups) >= max(len(m_) for m_ in T1.groups)      # the first step's merge survives the second
+    _check(spec, dcmotor_data(11), tape_oracle, SOLVE_ARGS, W, fuse="loop")
+
+
+def test_ldsm_stream_small_quadcopter_loop_merged(native_built, tape_oracle, tmp_path):
+    from tenscalc_amd.problems.mpc_quadcopter import SOLVE_ARGS, mpc_quadcopter, quadcopter_data
+    spec = mpc_quadcopter(T=8, classname="tmp_quadcopter8", folder=str(tmp_path))
+    _check(spec, quadcopter_data(2, T=8), tape_oracle, SOLVE_ARGS, W=4, fuse="loop")
