@@ -1578,7 +1578,7 @@ def _ldsc_byte_words(cs, two_phase=True, split_hbm=True):
     return [int(x) for x in words]
 
 
-def _ldsc_functions(cs, W, chunk=96, depth=8, trace=False):
+def _ldsc_functions(cs, W, chunk=96, depth=12, trace=False):
     from . import instructions as I
     from . import ldsm_schedule as lsch
     two_phase = os.environ.get("TC_LDSC_TWO_PHASE", "1") != "0"
@@ -1591,7 +1591,8 @@ def _ldsc_functions(cs, W, chunk=96, depth=8, trace=False):
     `depth` records ahead into one of `depth` register sets, barriers where the stream has them; cut into functions of
     `chunk` records (clang's time is superlinear in the size of a function).  tc_ldsm_run becomes a switch.
     mpc_quadcopter, 512 instances, ms per batch: interpreted walk (ldsm8) 531; compiled, 1 / 2 / 4 / 8 wavefronts per
-    instance at depth 4: 566 / 369 / 294 / 278; 4 wavefronts at depth 2 / 4 / 8 / 12 / 16: 323 / 294 / 276 / 275 / 277."""
+    instance at depth 4: 566 / 369 / 294 / 278; 4 wavefronts at depth 2 / 4 / 8 / 12 / 16: 323 / 294 / 276 / 275 / 277.
+    On the final round-4 stream (steps a third as long): depth 6 / 8 / 12 / 16 / 20: 165.7 / 156.5 / 152.0 / 153.5 / 152.0 -> 12."""
     # functions stay at `chunk` = 96 records: a build with 384 per function (mpc_quadcopter, W = 4) took a GPU memory
     # access fault on its first launch -- 20 k instructions per function, i.e. branch distances beyond the 16-bit
     # offsets; never investigated further, never run again
