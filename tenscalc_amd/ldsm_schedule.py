@@ -227,7 +227,8 @@ def loop_classes(T, defines):
                 inval[c_].add(e["name"])
     # ... and needed by the same entry points: the initialisation sequence is ONE position of the timeline, but a group
     # that scaleIneq__ needs must not be evaluated with one that initDualEqX__ needs -- its inputs are not there yet
-    # (the CPU model of tests/test_ldsm_stream.py caught exactly that on mpc_dcmotor)
+    # (the CPU model of tests/test_ldsm_stream.py caught exactly that on mpc_dcmotor; the tile machine, whose values have rows
+    # of their own, was tried on classes by position alone as well: l1l2 no longer bit-identical)
     needed = [set() for _ in range(nG + 1)]
     for e in list(T.gets) + list(T.copies):
         for p_ in e["parents"]:
