@@ -431,8 +431,8 @@ def assign_slots(T, defines, lds_slots=20000, stage=STAGE):
     # ranking: blocks the deep groups touch first, by reads per value (a cold value there stalls a latency-critical level);
     # the others by the number of STEPS that touch them per slot they would take -- a step with one operand in HBM
     # costs as much as one with sixty (round 4: mpc_quadcopter spent 13 % of an iteration in such steps)
+    # (weighting the groups the Newton loop never evaluates down to 0.05 was measured: no better than no ranking)
     touch = [set() for _ in blocks]
-    gw = {}           # (weighting the groups the Newton loop never evaluates down to 0.05 was measured: no better than no ranking)
     if os.environ.get("TC_LDSM_COLD_RANK", "1") != "0":
         bof = np.full(n + 1, -1, dtype=np.int64)
         for b, bl in enumerate(blocks):
@@ -446,7 +446,7 @@ def assign_slots(T, defines, lds_slots=20000, stage=STAGE):
             for j in opl[ost[i - 1]:ost[i]]:
                 if bof[j] >= 0:
                     touch[bof[j]].add(key)
-    score = [sum(gw.get(g_, 1.0) for g_, _ in touch[b]) / len(blocks[b]) for b in range(len(blocks))]
+    score = [len(touch[b]) / len(blocks[b]) for b in range(len(blocks))]
     order = sorted(range(len(blocks)), key=lambda b: (-float(np.mean(heat[blocks[b]])), -score[b]))
     hot, cold = [], []
     room = int(lds_slots) - lds
