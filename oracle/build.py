@@ -64,13 +64,17 @@ def build_ref(tag, defines, opt="-O1", solver="ipmPD_CSsolver"):
              "profiling"]
     dflags = ["-D%s=%s" % (k, _fmt(defines[k])) for k in names]
     dflags += ["-DverboseLevel=0", "-DEXPORT=", '-DsaveNamePrefix="x"']
-    obj = out[:-3] + ".o"
+    # intermediates and the library under process-private names, the library renamed into place: two test workers
+    # (pytest -n) asking for the same tag at the same time must not see each other's half-written files
+    obj = out[:-3] + ".%d.o" % os.getpid()
+    tmp = out + ".%d.tmp" % os.getpid()
     # the -D block only applies to the reference file; the glue and interpreter get none
     _run(["gcc", "-w", opt, "-ffp-contract=off", "-std=gnu99", "-fPIC", "-c"] + dflags + [ref, "-o", obj])
     _run(["gcc", opt, "-ffp-contract=off", "-std=gnu99", "-fPIC", "-shared", "-I", HERE, obj,
           os.path.join(HERE, "ref_glue.c"), os.path.join(HERE, "tc_oracle.c"), os.path.join(HERE, "tc_oracle_eq.c"),
-          "-o", out, "-lm"])
+          "-o", tmp, "-lm"])
     os.remove(obj)
+    os.replace(tmp, out)
     return out
 
 
@@ -87,8 +91,9 @@ def build_devloop(tag, defines, opt="-O1", solver="ipmPD_CSsolver"):
     out = os.path.join(HERE, "_ref", "libdevloop_%s.so" % tag)
     os.makedirs(os.path.join(HERE, "_ref"), exist_ok=True)
     csrc = os.path.join(os.path.dirname(HERE), "tenscalc_amd", "csrc")
-    obj = out[:-3] + ".o"
-    defs = out[:-3] + "_defs.h"
+    obj = out[:-3] + ".%d.o" % os.getpid()          # process-private names, see build_ref
+    defs = out[:-3] + ".%d_defs.h" % os.getpid()
+    tmp = out + ".%d.tmp" % os.getpid()
     with open(defs, "w") as f:
         f.write("".join("#define %s %s\n" % (k, _fmt(defines[k]))
                         for k in (EQ_DEFINE_NAMES if solver == "ipmPDeq_CSsolver" else DEFINE_NAMES)))
@@ -99,10 +104,10 @@ def build_devloop(tag, defines, opt="-O1", solver="ipmPD_CSsolver"):
           os.path.join(HERE, "tc_oracle.c"), "-o", obj[:-2] + "_o.o"])
     _run(["gcc", opt, "-ffp-contract=off", "-std=gnu99", "-fPIC", "-c", "-I", HERE,
           os.path.join(HERE, "tc_oracle_eq.c"), "-o", obj[:-2] + "_e.o"])
-    _run(["g++", "-shared", obj, obj[:-2] + "_o.o", obj[:-2] + "_e.o", "-o", out, "-lm"])
-    os.remove(obj)
-    os.remove(obj[:-2] + "_o.o")
-    os.remove(obj[:-2] + "_e.o")
+    _run(["g++", "-shared", obj, obj[:-2] + "_o.o", obj[:-2] + "_e.o", "-o", tmp, "-lm"])
+    for f_ in (obj, obj[:-2] + "_o.o", obj[:-2] + "_e.o", defs):
+        os.remove(f_)
+    os.replace(tmp, out)
     return out
 
 

@@ -1347,8 +1347,9 @@ class Tape:
         return Tape.from_instructions(self.types, self.opStart, self.ops, self.parStart, self.pars, sets, gets, copies,
                                       self.defines, ldl_stats=self.ldl_stats, merge=merge)
 
-    # static flop-class counts per group, same accounting as writeCinstructionsC
-    # (instructionsTableUTHash.c:816-832 and the countFlops_* updates in each case)
+    # static flop-class counts per group: the accounting of writeCinstructionsC, case by case
+    # (instructionsTableUTHash.c:816-832 for the classes, :962-1534 for the countFlops_* updates); the dynamic total of
+    # a solve -- the sum over executed groups, writeCfunctionpergroup.m:481-487 -- is what examples/flops.m:29-42 tabulates
     def _count_flops(self):
         cnt = np.zeros((self.nGroups + 1, 17), dtype=np.int64)
         ty, os_ = self.types, self.opStart
@@ -1359,58 +1360,61 @@ class Tape:
             t = int(ty[i - 1])
             no = int(os_[i] - os_[i - 1])
             c = cnt[g]
-            if t == I.I_sum:
+            if t == I.I_sum:                                                   # :962
                 c[I.P_nsum] += no - 1
-            elif t == I.I_sumprod:
+            elif t == I.I_sumprod:                                             # :1004-1005
                 m, s = self.pars[self.parStart[i - 1]:self.parStart[i]]
                 c[I.P_nsum] += int(s) - 1
                 c[I.P_nprod] += int(s) * (int(m) - 1)
-            elif t in (I.I_plus_minus_dot_div,):
-                k = (no - 2) // 2
-                c[I.P_nsum] += k
-                c[I.P_nprod] += k
+            elif t in (I.I_plus_minus_dot_div, I.I_minus_dot_div):           # :1077-1079, :1102-1104
+                c[I.P_nsum] += (no - 1) // 2
+                c[I.P_nprod] += (no - 1) // 2
                 c[I.P_ndiv] += 1
-            elif t == I.I_minus_dot_div:
-                k = (no - 1) // 2
-                c[I.P_nsum] += k
-                c[I.P_nprod] += k
+            elif t in (I.I_plus_minus_dot, I.I_minus_dot):                   # :1125-1126, :1148-1149: C integer division,
+                c[I.P_nsum] += (no - 1) // 2                                   # so I_minus_dot (2k operands) counts k-1
+                c[I.P_nprod] += (no - 1) // 2
+            elif t in (I.I_div, I.I_inv):                                     # :1170, :1428
                 c[I.P_ndiv] += 1
-            elif t == I.I_plus_minus_dot:
-                k = (no - 1) // 2
-                c[I.P_nsum] += k
-                c[I.P_nprod] += k
-            elif t == I.I_minus_dot:
-                k = no // 2
-                c[I.P_nsum] += k
-                c[I.P_nprod] += k
-            elif t in (I.I_div, I.I_inv):
-                c[I.P_ndiv] += 1
-            elif t == I.I_plus_sqr:
+            elif t == I.I_plus_sqr:                                            # :1198-1199
                 c[I.P_nsum] += no - 1
                 c[I.P_nprod] += no
-            elif t == I.I_plus_abs:
+            elif t == I.I_plus_abs:                                            # :1214-1215
                 c[I.P_nsum] += no - 1
                 c[I.P_nabs] += no
-            elif t in (I.I_min, I.I_max, I.I_min0, I.I_max0):
+            elif t in (I.I_min, I.I_max):                                     # :1229-1230, :1263-1264
+                c[I.P_nsum] += no - 1
+                c[I.P_nif] += no - 1
+            elif t in (I.I_min0, I.I_max0):                                   # :1247-1248, :1281-1282
+                c[I.P_nsum] += no
                 c[I.P_nif] += no
-            elif t == I.I_max_abs:
-                c[I.P_nif] += no
+            elif t == I.I_max_abs:                                             # :1297-1299
+                c[I.P_nsum] += no - 1
+                c[I.P_nif] += no - 1
                 c[I.P_nabs] += no
-            elif t == I.I_clp:
-                c[I.P_nclp] += no // 2
-                c[I.P_ndiv] += no // 2
+            elif t == I.I_clp:                                                 # :1316
+                c[I.P_nclp] += no
+            elif t == I.I_round:
+                c[I.P_nround] += 1
+            elif t == I.I_ceil:
+                c[I.P_nceil] += 1
+            elif t == I.I_floor:
+                c[I.P_nfloor] += 1
             elif t == I.I_abs:
                 c[I.P_nabs] += 1
-            elif t in (I.I_sqrt,):
+            elif t == I.I_sign:
+                c[I.P_nsign] += 1
+            elif t in (I.I_2, I.I_zero):                                      # :1378: no count
+                pass
+            elif t == I.I_sqrt:
                 c[I.P_nsqrt] += 1
-            elif t in (I.I_Dsqrt, I.I_DDsqrt):
+            elif t in (I.I_Dsqrt, I.I_DDsqrt):                                # :1416-1417, :1422-1423
                 c[I.P_npow] += 1
                 c[I.P_nprod] += 1
             elif t in (I.I_sqr, I.I_2times, I.I_6times):
                 c[I.P_nprod] += 1
             elif t in (I.I_cube, I.I_3sqr):
                 c[I.P_nprod] += 2
-            elif t in (I.I_minus_inv_sqr,):
+            elif t == I.I_minus_inv_sqr:
                 c[I.P_nprod] += 1
                 c[I.P_ndiv] += 1
             elif t == I.I_2_inv_cube:
@@ -1422,11 +1426,97 @@ class Tape:
                 c[I.P_nlog] += 1
             elif t == I.I_exp:
                 c[I.P_nexp] += 1
-            elif t in (I.I_heaviside, I.I_relu, I.I_sign):
+            elif t == I.I_Datan:                                               # :1489-1491
+                c[I.P_ndiv] += 1
+                c[I.P_nsum] += 1
+                c[I.P_nprod] += 1
+            elif t == I.I_DDatan:                                              # :1497-1499
+                c[I.P_ndiv] += 2
+                c[I.P_nsum] += 2
+                c[I.P_nprod] += 3
+            elif t == I.I_srelu:
+                c[I.P_nexp] += 1
+                c[I.P_nlog] += 1
+            elif t == I.I_dsrelu:
+                c[I.P_nexp] += 1
+                c[I.P_ndiv] += 1
+            elif t == I.I_ddsrelu:
+                c[I.P_nexp] += 2
+                c[I.P_ndiv] += 1
+                c[I.P_nsum] += 1
+            elif t in (I.I_heaviside, I.I_relu):
                 c[I.P_nif] += 1
-            else:
+            else:                                                              # I_componentwise :1334
                 c[I.P_cpwise] += 1
         return cnt
+
+    def reference_memory_map(self):
+        """The reference's instruction -> scratchbook map (dependencyGroups.m:275-422), restated for comparison with
+        `code.statistics.sizeScratchbook` (examples/flops.m:121): every instruction starts with a location of its own
+        (sets and constants included, :277); inside each dependency group a *local* variable -- no reader outside the
+        group, not the source of a get / copy (:316-319) -- takes, in instruction order, the first location of an
+        earlier local variable whose last reader precedes it (:357-375), the location it gives up is never handed
+        out again (:373); holes are then compressed (:405-422).  Returns (location per instruction, 1-based ids, 0-based
+        locations, -1 for none; sizeScratchbook).  The lowerings here have memory maps of their own (lowering.py,
+        ldsm_schedule.py); this one exists to be checked against the reference's number."""
+        n = self.n
+        ost, opl = self.opStart.tolist(), self.ops.tolist()
+        grp = self.group
+        last_user = np.zeros(n + 1, dtype=np.int64)
+        outside = np.zeros(n + 1, dtype=bool)
+        for i in range(1, n + 1):
+            gi = grp[i]
+            for j in opl[ost[i - 1]:ost[i]]:
+                if i > last_user[j]:
+                    last_user[j] = i
+                if grp[j] != gi:
+                    outside[j] = True
+        outs = np.zeros(n + 1, dtype=bool)
+        for e in self.gets:
+            for o in e["outputs"]:
+                outs[o["ins"]] = True
+        for e in self.copies:
+            outs[e["src"]] = True
+        loc = np.arange(n + 1, dtype=np.int64)
+        INF = np.iinfo(np.int64).max
+        # unused instructions share the reference's all-zero dependency row, i.e. one more group (:111-116)
+        members_of = [np.flatnonzero((grp == 0) & np.r_[False, ~self.isset])] + list(self.groups)
+        for members in members_of:
+            lv = [int(i) for i in members if not outside[i] and not outs[i]]
+            m = len(lv)
+            if m < 2:
+                continue
+            last = [int(last_user[i]) if last_user[i] > 0 else INF for i in lv]
+            size = 1
+            while size < m:
+                size *= 2
+            tree = [INF] * (2 * size)          # min segment tree over lastUsedMemory: "first i with value < v"
+            for k in range(m):
+                tree[size + k] = last[k]
+            for k in range(size - 1, 0, -1):
+                tree[k] = min(tree[2 * k], tree[2 * k + 1])
+
+            def put(k, v):
+                k += size
+                tree[k] = v
+                k //= 2
+                while k:
+                    tree[k] = min(tree[2 * k], tree[2 * k + 1])
+                    k //= 2
+
+            for j, v in enumerate(lv):
+                if tree[1] >= v:
+                    continue
+                k = 1
+                while k < size:
+                    k = 2 * k if tree[2 * k] < v else 2 * k + 1
+                i2 = k - size
+                loc[v] = lv[i2]                 # localMemory(i): the location variable i2 started with
+                put(i2, last[j])
+                put(j, INF)
+        _, inv = np.unique(loc[1:], return_inverse=True)
+        out = np.r_[-1, inv].astype(np.int64)
+        return out, int(inv.max()) + 1 if n else 0
 
     def flops_of_groups(self, groups):
         """nsum+nprod+ndiv+... for a list of 1-based group ids"""

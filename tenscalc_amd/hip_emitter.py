@@ -1247,7 +1247,10 @@ def emit_class(spec, fp_contract="fast", block=64, stats=False, roll=True, min_w
              "#else  // diagnostic build: wall cycles (s_memtime) and call count per dependency group\n"
              "#define TC_NEED(g) do { if (!((c.st[((g)-1)>>6] >> (((g)-1)&63)) & 1ull)) { "
              "c.st[((g)-1)>>6] |= 1ull << (((g)-1)&63); const long long t0_ = clock64(); TC_CALL_GRP##g; "
-             "c.cyc[(g)-1] += clock64() - t0_; c.cnt[(g)-1]++; } } while (0)\n#endif\n")
+             "c.cyc[(g)-1] += clock64() - t0_; c.cnt[(g)-1]++; } } while (0)\n"
+             "#undef TC_EVAL   // ... the executions the static schedule knows to be needed count too (the profile's totals)\n"
+             "#define TC_EVAL(g) do { c.st[((g)-1)>>6] |= 1ull << (((g)-1)&63); const long long t0_ = clock64(); TC_CALL_GRP##g; "
+             "c.cyc[(g)-1] += clock64() - t0_; c.cnt[(g)-1]++; } while (0)\n#endif\n")
 
     # Groups that use lane-distributed register state must be inlined wherever they are evaluated.
     # To keep ONE copy of their code per invalidation point instead of one per reader they are
@@ -1523,7 +1526,7 @@ def emit_class(spec, fp_contract="fast", block=64, stats=False, roll=True, min_w
     w.append("    default: break;\n  }\n}\n\n")
     if lds_state and lanes == 1 and not roll and not interp:
         w = [_place_state_in_lds("".join(w), T, L, spec, int(lds_state))]
-    w.append(_class_tail(spec, T, L, out_meta, probes, lanes, nOut))
+    w.append(_class_tail(spec, T, L, out_meta, probes, lanes, nOut, stats=stats))
     return "".join(w), L
 
 
@@ -1890,7 +1893,7 @@ def emit_class_ldsm(spec, waves=4, stats=False, lds_slots=20000, fuse_chain=True
     for o in outs:
         out_meta.append((o["name"], o["size"], len(o["ins"]), off))
         off += len(o["ins"])
-    w.append(_class_tail(spec, T, L, out_meta, [], 1, nOut))
+    w.append(_class_tail(spec, T, L, out_meta, [], 1, nOut, stats=stats))
     return "".join(w), L
 
 
@@ -1932,7 +1935,7 @@ def _place_state_in_lds(src, T, L, spec, budget):
     return head + f"#define TC_NLS {max(1, len(cand))}\n#define MM(k)" + body
 
 
-def _class_tail(spec, T, L, out_meta, probes, lanes, nOut):
+def _class_tail(spec, T, L, out_meta, probes, lanes, nOut, stats=False):
     """metadata tables + reference-name wrappers + the host runtime (shared by every back-end)"""
     cls = spec.classname
     w = []
@@ -1978,6 +1981,12 @@ def _class_tail(spec, T, L, out_meta, probes, lanes, nOut):
             "output_doubles": int(nOut), "flops_all_groups": int(T.flops.sum())}
     for g in range(1, T.nGroups + 1):
         stat[f"flops_group{g}"] = int(T.flops[g].sum())
+    if stats and {"phases": 2, "trace": 3, "levels": 4}.get(stats, 1) == 1:
+        # operations by class per dependency group (Tape._count_flops = the accounting of writeCinstructionsC): the
+        # profiling view turns the execution counts of a solve into the reference's "Operation Count" table
+        w.append("static const int64_t TC_GRP_FLOPS[][17] = {"
+                 + ", ".join("{" + ", ".join(str(int(x)) for x in T.flops[g]) + "}" for g in range(1, T.nGroups + 1)) + "};\n")
+        stat["reference_scratchbook"] = int(T.reference_memory_map()[1])
     w.append(f"static const int TC_NSTAT = {len(stat)};\n")
     w.append(carr("char *const", "TC_STAT_NAME", list(stat), lambda s: f'"{s}"'))
     w.append(carr("int64_t", "TC_STAT_VAL", list(stat.values())))
