@@ -24,6 +24,23 @@ ALGO_BYTES_PER_SOLVE = 8 * (800 + 100 + 8) + 8 * (1 + 8) + 8   # 7
 HBM_PEAK_GBPS = 8000.0                                           # MI355X_MICROARCH.md chip table
 
 
+_POW_CHECK = {}
+
+
+def parity_fields(label, tape, defines):
+    """config.parity_class, checked: a "bit-exact" label is printed only if the device's pow replacements return this host's
+    pow on 2e5 arguments -- once per process, on the GPU when there is one (tenscalc_amd/tools/powcheck.py); the outcome
+    rides along as config.libm_check.  TC_BENCH_STANDIN rehearsals have no device and check the host build."""
+    from tenscalc_amd.tools.powcheck import checked_parity_class, pow_parity, tape_calls_pow
+    if label == "bit-exact" and any(tape_calls_pow(tape, defines)) and "r" not in _POW_CHECK:
+        _POW_CHECK["r"] = pow_parity(device=False if os.environ.get("TC_BENCH_STANDIN") else None)
+    label, chk = checked_parity_class(label, tape, defines, check=_POW_CHECK.get("r"))
+    out = {"parity_class": label}
+    if chk is not None:
+        out["libm_check"] = chk
+    return out
+
+
 class _DevArray:
     """zero-copy view of handle-owned device memory for torch (cuda array interface v2)"""
 
@@ -179,6 +196,18 @@ class _StandInSolver:
 
     def close(self):
         pass
+
+
+class _StandInConfigSolver(_StandInSolver):
+    """the same for `bench_config`: the handle surface that function uses (set from host arrays, outputs, views)"""
+
+    def __init__(self, B, spec):
+        self.outputs = [{"name": n_, "numel": int(__import__("numpy").prod(sz)) if len(sz) else 1} for n_, sz in spec.outputs]
+        super().__init__(B, sum(o["numel"] for o in self.outputs))
+
+    def set(self, name, arr):
+        import torch
+        self.inputs[name] = torch.as_tensor(arr, dtype=torch.float64).reshape(self.B, -1).T.contiguous()     # [numel][B]
 
 
 def main():
@@ -392,7 +421,7 @@ def bench_sls(args, R):
                                        else "batch=%d per GPU" % B)),
                        "batch_per_gpu": B, "batch_total": total, "mu0": SOLVE_ARGS["mu0"], "maxIter": SOLVE_ARGS["maxIter"],
                        "variant": args.variant,
-                       "parity_class": g.PARITY_CLASS.get(args.variant, "solver-tolerance"),
+                       **parity_fields(g.PARITY_CLASS.get(args.variant, "solver-tolerance"), spec.tape, spec.defines),
                        "tape": ("hoisted (parameter-only contractions first); results within the stated tolerance of the "
                                 "reference tape, tests/test_gpu_parity.py" if args.variant in g.HOISTED else "reference"),
                        "solved_fraction": solved_per_step / total,
@@ -602,9 +631,10 @@ def bench_config(args, R):
     import __graft_entry__ as g
     from tenscalc_amd.runtime import HipSolver
     from tenscalc_amd.sharding import pack_results, reduce_timing, shard_range
-    if R.standin:
-        raise SystemExit("bench.py: TC_BENCH_STANDIN rehearses the sls line only")
     rank, world, local, dev, dist = R.rank, R.world, R.local, R.dev, R.dist
+    # TC_BENCH_STANDIN: the same control flow -- shards of a --total, padding of unequal shards, the one gather, the
+    # reduction -- with a stand-in for the per-rank solver and gloo on CPU tensors (tests/test_bench_launcher.py)
+    standin = R.standin
     modname, mk, datafn, B0, var0, ncpu, label = CONFIGS[args.config]
     mod = importlib.import_module(modname)
     SOLVE = mod.SOLVE_ARGS
@@ -619,26 +649,41 @@ def bench_config(args, R):
         variant = "w32x"      # one GPU's share of the 8-GPU sweep: the wave-cooperative lowering (LDS-resident state) wins
     spec = getattr(mod, mk)(folder=g.GENERATED)
     kw = dict(g.VARIANT_KW[variant])
-    if rank == 0:
-        spec.build(**kw)
-    R.barrier()
-    so = spec.build(**kw)
+    if not standin:
+        if rank == 0:
+            spec.build(**kw)
+        R.barrier()
+        so = spec.build(**kw)
     names = [n for n, _ in spec.parameters + spec.variables]
     ds = [getattr(mod, datafn)(lo + k) for k in range(B)]                     # distinct instances, seed = global id
     stacked = {n: np.stack([np.asarray(d[n], dtype=float).reshape(-1, order="F") for d in ds]) for n in names}
     del ds
     P = max(1, int(args.pipeline))
-    objs = [HipSolver(so, B=B, device=local) for _ in range(P)]
+    objs = [(_StandInConfigSolver(B, spec) if standin else HipSolver(so, B=B, device=local)) for _ in range(P)]
     for o_ in objs:
         for n in names:
             o_.set(n, stacked[n])
     obj = objs[0]
+
+    class _NoStream:        # stand-in: nothing is asynchronous
+        cuda_stream = None
+
+        def wait_stream(self, other):
+            pass
     # one torch stream per slot (P == 1: torch's current stream, which is where the kernel events are recorded)
-    streams = [torch.cuda.current_stream()] if P == 1 else [torch.cuda.Stream(device=dev) for _ in range(P)]
+    if standin:
+        streams = [_NoStream() for _ in range(P)]
+        cur_stream = _NoStream
+    else:
+        streams = [torch.cuda.current_stream()] if P == 1 else [torch.cuda.Stream(device=dev) for _ in range(P)]
+        cur_stream = torch.cuda.current_stream
     ae = SOLVE.get("addEye2Hessian", (1e-9, 1e-9))
     nout = sum(o["numel"] for o in obj.outputs)
     views = []
     for o_ in objs:
+        if standin:
+            views.append((o_.O, o_.ST, o_.IT))
+            continue
         optr, sptr, iptr = o_.device_views()
         views.append((torch.as_tensor(_DevArray(optr, (nout, B), "<f8"), device=dev),
                       torch.as_tensor(_DevArray(sptr, (B,), "<i4"), device=dev),
@@ -654,30 +699,33 @@ def bench_config(args, R):
         return p_
     for k in range(args.warmup * P):
         objs[k % P].solve_async(SOLVE["mu0"], SOLVE["maxIter"], ae, stream=streams[k % P].cuda_stream)
-    evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(args.steps)]
+    evs = [] if standin else [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+                              for _ in range(args.steps)]
     gathered = None
     if world > 1:      # one untimed gather of the same shape: RCCL sets up its channels at the first collective
         gathered = torch.empty((world, nout + 2, Bmax), dtype=torch.float64, device=dev)
         for s_ in streams:
-            torch.cuda.current_stream().wait_stream(s_)
+            cur_stream().wait_stream(s_)
         dist.all_gather_into_tensor(gathered.view(world * (nout + 2), Bmax), packed().contiguous())
     R.barrier()
-    torch.cuda.synchronize()
+    R.sync()
     t0 = time.perf_counter()
     for k in range(args.steps):
         s_ = streams[k % P]
-        evs[k][0].record(s_)
+        if evs:
+            evs[k][0].record(s_)
         objs[k % P].solve_async(SOLVE["mu0"], SOLVE["maxIter"], ae, stream=s_.cuda_stream)
-        evs[k][1].record(s_)
+        if evs:
+            evs[k][1].record(s_)
     if P > 1:
         for s_ in streams:
-            torch.cuda.current_stream().wait_stream(s_)
+            cur_stream().wait_stream(s_)
     if world > 1:      # the path's only exchange: one gather of status / iteration counts / outputs after the K steps
         dist.all_gather_into_tensor(gathered.view(world * (nout + 2), Bmax), packed().contiguous())
-    torch.cuda.synchronize()
+    R.sync()
     if world > 1:
         R.barrier()
-        torch.cuda.synchronize()
+        R.sync()
     elapsed = time.perf_counter() - t0
     ok_all = [int((v[1] == 0).sum().item()) for v in views[:min(P, args.steps)]]      # status of EVERY handle in flight
     elapsed, ok = reduce_timing(elapsed, float(np.mean(ok_all)), world, dev)
@@ -687,7 +735,7 @@ def bench_config(args, R):
         st = ST.cpu().numpy()
         nin = sum(int(np.prod(s_)) if len(s_) else 1 for _, s_ in spec.parameters + spec.variables)
         algo = 8 * (nin + nout) + 8                               # inputs + outputs + (status, iter)
-        if P == 1:
+        if P == 1 and evs:
             kavg = float(np.mean([a.elapsed_time(b_) for a, b_ in evs])) * 1e-3
             kernel_note = "HIP events around each launch on the launch stream"
         else:       # spans of overlapping launches include the time spent sharing the chip: use the whole-region rate
@@ -702,7 +750,7 @@ def bench_config(args, R):
                "dtype": "f64", "data": "synthetic",
                "config": {"workload": (label % B) + (" [--total %d sharded over %d GPU(s)]" % (args.total, world) if args.total else ""),
                           "batch_per_gpu": B, "batch_total": total, "mu0": SOLVE["mu0"], "maxIter": SOLVE["maxIter"],
-                          "variant": variant, "parity_class": g.PARITY_CLASS.get(variant, "solver-tolerance"),
+                          "variant": variant, **parity_fields(g.PARITY_CLASS.get(variant, "solver-tolerance"), spec.tape, spec.defines),
                           "pipeline": P, "distinct_instances": B,
                           "solved_fraction": ok / total, "iter_median": float(np.median(it)),
                           "iter_max": int(it.max()), "devices": R.devices,
@@ -711,7 +759,13 @@ def bench_config(args, R):
                             "frac": achieved / HBM_PEAK_GBPS, "traffic": measured_traffic(args.config + "_" + variant, B),
                             "kernel": "tc_solve_kernel", "kernel_ms_avg": kavg * 1e3, "kernel_ms_from": kernel_note,
                             "algorithmic_bytes_per_launch": algo * B, "algorithmic_bytes_per_solve": algo}}
-        if not args.no_cpu and world == 1:
+        if standin:
+            out["data"] = "STAND-IN: no solver ran (TC_BENCH_STANDIN rehearsal of the multi-rank control flow)"
+            out["standin"] = True
+            if gathered is not None:       # what the one gather delivered to rank 0, for the rehearsal's checks
+                out["gathered"] = {"status": gathered[:, nout].to(torch.int32).tolist(),
+                                   "checksum": gathered[:, 0].tolist(), "shard": [lo, lo + B]}
+        if not args.no_cpu and world == 1 and not standin:
             out["cpu_baseline"] = cpu_baseline_config(spec, args.config, stacked, names, min(B, ncpu), SOLVE, st, it,
                                                       budget_s=getattr(args, "cpu_budget_s", 8.0))
     for o_ in objs:

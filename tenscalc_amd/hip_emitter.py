@@ -1478,6 +1478,10 @@ def emit_class(spec, fp_contract="fast", block=64, stats=False, roll=True, min_w
             out_meta.append((o["name"], o["size"], len(o["ins"]), off))
             off += len(o["ins"])
     else:
+        # profiling builds: what the Newton loop alone executed (the reference's solve() does not evaluate the outputs;
+        # the batched kernel does, in the same launch) -- rows [2G+10, 3G+10) of the stats buffer
+        w.append("#if defined(TC_STATS) && TC_STATS == 1\n#define TC_STATS_LOOPCNT 1\n  int cntLoop_[TC_NGROUPS];\n"
+                 "  for (int k = 0; k < TC_NGROUPS; k++) cntLoop_[k] = c.cnt[k];\n#endif\n")
         for k, o in enumerate(outs):
             w.append(f"  double y{k + 1}[{max(1, len(o['ins']))}];\n")
         w.append(f"  {cls}_getOutputs{full}(c, " + ", ".join(f"y{k + 1}" for k in range(len(outs))) + ");\n")
@@ -1493,7 +1497,9 @@ def emit_class(spec, fp_contract="fast", block=64, stats=False, roll=True, min_w
              "      dbg[(long)k * B + tid] = (double)c.cyc[k];\n      dbg[(long)(TC_NGROUPS + k) * B + tid] = (double)c.cnt[k];\n    }\n"
              "    dbg[(long)(2 * TC_NGROUPS) * B + tid] = (double)(clock64() - tstart_);\n"
              "    dbg[(long)(2 * TC_NGROUPS + 1) * B + tid] = (double)c.nMinF;\n"
-             "    for (int k = 0; k < 8; k++) dbg[(long)(2 * TC_NGROUPS + 2 + k) * B + tid] = (double)c.ph[k];\n  }\n#endif\n}\n\n")
+             "    for (int k = 0; k < 8; k++) dbg[(long)(2 * TC_NGROUPS + 2 + k) * B + tid] = (double)c.ph[k];\n"
+             "#ifdef TC_STATS_LOOPCNT\n    for (int k = 0; k < TC_NGROUPS; k++) dbg[(long)(2 * TC_NGROUPS + 10 + k) * B + tid] = (double)cntLoop_[k];\n#endif\n"
+             "  }\n#endif\n}\n\n")
     # probe kernel: init sequence then one get
     w.append("extern \"C\" __global__ void __launch_bounds__(TC_BLOCK)\n"
              "tc_probe_kernel(const double *__restrict__ S, const double *__restrict__ Sd, double *__restrict__ out,\n"
@@ -2061,7 +2067,7 @@ def build_class(spec, fp_contract="fast", arch="gfx950", opt="-O3", block=64, fo
     kq.update(repr((cls, sorted(spec.defines.items()), [(n, tuple(sz)) for n, sz in spec.outputs], fp_contract, arch, opt, block,
                     stats, tag, tuple(extra_flags), roll, min_waves, lanes, recip, fast_div, inline_max, reg_budget, scratch,
                     body, waves, fuse, static_clean, forward, rcache, lds_state, share, branch_free_tails, exact, stg_blocks,
-                    lds_slots, ilp, fw_window, sched_every, tuple(try_flags), refresh_outputs, compiled, os.environ.get("TC_LDS_PAD_SLOTS", ""), os.environ.get("TC_STG_BATCH", ""), os.environ.get("TC_LDSM_FUSE", ""), os.environ.get("TC_INTERP_FUSE", ""), os.environ.get("TC_LDSM_LOOP_MERGE", ""), os.environ.get("TC_LDSC_DEPTH", ""), os.environ.get("TC_LDSM_PACK_LOCALS", ""), os.environ.get("TC_LDSM_ROW_SKEW", ""), os.environ.get("TC_LDSM_LATE_LAST", ""), os.environ.get("TC_LDSM_PAD_PRODUCTS", ""), os.environ.get("TC_LDSM_MERGE_PRODUCTS", ""), os.environ.get("TC_LDSM_COLD_RANK", ""), os.environ.get("TC_LDSC_TWO_PHASE", ""), os.environ.get("TC_LDSC_SPLIT_HBM", ""), os.environ.get("TC_LDSC_SCHEDB", ""), os.environ.get("TC_LDSC_BYTES", ""), os.environ.get("TC_LDSC_WPE", ""),
+                    lds_slots, ilp, fw_window, sched_every, tuple(try_flags), refresh_outputs, compiled, os.environ.get("TC_LDS_PAD_SLOTS", ""), os.environ.get("TC_STG_BATCH", ""), os.environ.get("TC_LDSM_FUSE", ""), os.environ.get("TC_INTERP_FUSE", ""), os.environ.get("TC_LDSM_LOOP_MERGE", ""), os.environ.get("TC_LDSC_DEPTH", ""), os.environ.get("TC_LDSM_PACK_LOCALS", ""), os.environ.get("TC_LDSM_ROW_SKEW", ""), os.environ.get("TC_LDSM_LATE_LAST", ""), os.environ.get("TC_LDSM_PAD_PRODUCTS", ""), os.environ.get("TC_LDSM_MERGE_PRODUCTS", ""), os.environ.get("TC_LDSM_COLD_RANK", ""), os.environ.get("TC_LDSC_TWO_PHASE", ""), os.environ.get("TC_LDSC_SPLIT_HBM", ""), os.environ.get("TC_LDSC_SCHEDB", ""), os.environ.get("TC_LDSC_BYTES", ""), os.environ.get("TC_LDSC_WPE", ""), os.environ.get("TC_LDSM_STAGE", ""),
                     os.environ.get("TC_SWEEP_UNROLL", ""))).encode())
     for f_ in sorted(os.listdir(HERE)):
         if f_.endswith(".py"):

@@ -307,6 +307,7 @@ def assign_slots(T, defines, lds_slots=20000, stage=STAGE):
     """-> dict(addr=int array [n+1] (-1: no storage), nLds, nGlob, nExt, consts=[(addr, value)],
     inputs=[(first global index, numel, entry name)], dummy=LDS slot nobody reads, ...)"""
     from .lowering import Lowering
+    stage = int(os.environ.get("TC_LDSM_STAGE", stage))      # staging slots: tapes without long folds need few
     L = Lowering(T, None, roll=False, lanes=1, spill_all=True)
     n = T.n
     grp = T.group

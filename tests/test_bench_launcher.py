@@ -58,3 +58,33 @@ def test_world_size_must_match_gpus(native_built):
 def test_default_is_one_gpu_and_batch_total_exclusive(native_built):
     r = _bench("--batch", 8, "--total", 8)
     assert r.returncode != 0 and "exclude" in r.stderr
+
+
+def test_config_runs_are_rehearsed_too(native_built):
+    """`bench.py --gpus N --config dcmotor --total T` -- BASELINE configs[3] / [4] are stated as 8-GPU totals -- through the
+    same stand-in: contiguous unequal shards of distinct instances (seed = global id), padding columns carry status -1,
+    ONE gather delivers every rank's results to rank 0, solves summed over the ranks, max-over-ranks time"""
+    r = _bench("--gpus", 3, "--config", "dcmotor", "--total", 50, "--steps", 2, "--warmup", 1, "--no-cpu", timeout=600)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1
+    d = json.loads(lines[0])
+    assert d["standin"] is True and d["n_gpus"] == 3 and d["scaling"] == "strong" and d["steps"] == 2
+    cfg = d["config"]
+    assert cfg["batch_total"] == 50 and cfg["batch_per_gpu"] == 17 and cfg["solved_fraction"] == 1.0      # 17 / 17 / 16
+    assert "--total 50 sharded over 3" in cfg["workload"] and len(set(cfg["devices"])) == 3
+    g_ = d["gathered"]
+    st = g_["status"]
+    assert [len(row) for row in st] == [17, 17, 17] and g_["shard"] == [0, 17]
+    assert all(v == 0 for v in st[0] + st[1] + st[2][:16]) and st[2][16] == -1               # the one padding column
+    sums = g_["checksum"]
+    flat = sums[0] + sums[1] + sums[2][:16]
+    assert len(set(round(v, 9) for v in flat)) == 50                                             # 50 distinct instances arrived
+    assert abs(d["value"] - 50 * 2 / (d["ms_per_step"] * 2e-3)) <= 1e-6 * d["value"]
+
+
+def test_config_single_rank_standin(native_built):
+    r = _bench("--config", "dcmotor", "--batch", 8, "--steps", 1, "--warmup", 0, "--no-cpu", timeout=600)
+    assert r.returncode == 0, r.stderr[-3000:]
+    d = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
+    assert d["standin"] is True and d["n_gpus"] == 1 and d["config"]["batch_total"] == 8 and "gathered" not in d

@@ -3,45 +3,11 @@ reference's `.5*pow(x,-.5)` / `-.25*pow(x,-1.5)`, instructionsTableUTHash.c:1418
 file against exact integer arithmetic, and against the host libm's pow."""
 import ctypes
 import math
-import os
-import subprocess
 
 import numpy as np
 import pytest
 
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-HERE = os.path.join(ROOT, "tests", "crmath")
-
-
-def build_host():
-    out = os.path.join(HERE, "libcrmath_host.so")
-    csrc = os.path.join(ROOT, "tenscalc_amd", "csrc")
-    srcs = [os.path.join(HERE, "crmath_host.c"), os.path.join(csrc, "tc_crmath.hip.inc"),
-            os.path.join(csrc, "tc_glibcpow.hip.inc"), os.path.join(csrc, "tc_glibcpow_tables.inc")]
-    if not os.path.exists(out) or os.path.getmtime(out) < max(map(os.path.getmtime, srcs)):
-        subprocess.run(["gcc", "-O1", "-ffp-contract=off", "-std=gnu99", "-fPIC", "-shared", "-I",
-                        os.path.dirname(srcs[1]), srcs[0], "-o", out, "-lm"], check=True)
-    return ctypes.CDLL(out)
-
-
-def build_dev():
-    """hipcc build of the same files for gfx950 (cross-compiles without a GPU; __graft_entry__.build() calls this)"""
-    out = os.path.join(HERE, "libcrmath_dev.so")
-    csrc = os.path.join(ROOT, "tenscalc_amd", "csrc")
-    srcs = [os.path.join(HERE, "crmath_dev.hip")] + [os.path.join(csrc, f) for f in
-            ("tc_pow.hip.inc", "tc_crmath.hip.inc", "tc_glibcpow.hip.inc", "tc_glibcpow_tables.inc")]
-    if not os.path.exists(out) or os.path.getmtime(out) < max(map(os.path.getmtime, srcs)):
-        subprocess.run([os.environ.get("HIPCC", "/opt/rocm/bin/hipcc"), "-O3", "--offload-arch=gfx950", "-std=c++17",
-                        "-ffp-contract=off", "-fPIC", "-shared", "-I", csrc, srcs[0], "-o", out], check=True)
-    return out
-
-
-def _eval(fn, x):
-    x = np.ascontiguousarray(x, dtype=np.float64)
-    a, b = np.empty_like(x), np.empty_like(x)
-    dp = ctypes.POINTER(ctypes.c_double)
-    fn(x.ctypes.data_as(dp), a.ctypes.data_as(dp), b.ctypes.data_as(dp), ctypes.c_long(x.size))
-    return a, b
+from tenscalc_amd.tools.powcheck import build_dev, build_host, eval2 as _eval, sample      # noqa: E402
 
 
 def exact_power(x, three):
@@ -63,13 +29,6 @@ def exact_power(x, three):
     if rest > half:
         hi += 1
     return math.ldexp(hi, sh - K)
-
-
-def sample(n, seed):
-    r = np.random.RandomState(seed)
-    x = np.concatenate([r.uniform(1e-3, 500, n // 2), np.exp(r.uniform(-60, 60, n // 4)),
-                        r.uniform(0.5, 2.0, n - n // 2 - n // 4)])
-    return x
 
 
 def test_correctly_rounded_against_exact_arithmetic():

@@ -134,7 +134,7 @@ def test_profiling_view_through_the_boundary(tmp_path):
             obj.profilingView(path)
             txt = open(path).read().splitlines()
             assert txt[0].split() == ["Operation", "Count"] and txt[18].split()[0] == "Total"      # writeCprofiling.c:16-22
-            txt = txt[19:]
+            txt = txt[[k for k, ln in enumerate(txt) if ln.startswith("Group ")][0]:]
             rows = [ln.split() for ln in txt[1:1 + spec.tape.nGroups]]
             assert [int(r[0]) for r in rows] == list(range(spec.tape.nGroups))
             execs = np.array([float(r[2]) for r in rows]); tus = np.array([float(r[3]) for r in rows])
