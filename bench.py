@@ -239,7 +239,7 @@ def main():
     ap.add_argument("--config", default="sls", choices=["sls", "l1l2", "dcmotor", "quadcopter"],
                     help="sls (default): BASELINE.json's metric, configs[1].  The others are BASELINE configs[2..4] in the "
                          "same JSON vocabulary: l1l2 16384 instances, dcmotor 32768 (the whole 8-GPU sweep on one GPU), "
-                         "quadcopter 512 (configs[4]'s per-GPU share of 4096) per GPU; --batch / --total override")
+                         "quadcopter 4096 (configs[4]; --batch 512 = its per-GPU share over 8 GPUs) per GPU; --batch / --total override")
     ap.add_argument("--pipeline", type=int, default=1,
                     help="--config runs only: number of batches in flight (that many solver handles, each on a stream of "
                          "its own, steps issued round-robin).  1 (default) = one batched solve after the other.  With >1 the "
@@ -271,11 +271,13 @@ def main():
                 and args.variant == g.BENCH_DEFAULT):
             # BASELINE configs[2..4] ride along in the driver-timed invocation: 3 steps each, bounded CPU samples
             out["configs"] = {}
-            for name in ("l1l2", "dcmotor", "quadcopter"):
+            for name in ("l1l2", "dcmotor", "quadcopter", "quadcopter_share512"):
                 t0 = time.perf_counter()
                 try:
-                    sub = argparse.Namespace(**dict(vars(args), config=name, variant="", steps=3, warmup=1, pipeline=1,
-                                                    cpu_budget_s=4.0))
+                    sub = argparse.Namespace(**dict(vars(args), config=name.split("_")[0], variant="", steps=3, warmup=1,
+                                                    pipeline=1, cpu_budget_s=4.0))
+                    if name == "quadcopter_share512":        # one GPU's share of configs[4] over 8 GPUs; CPU figure: see above
+                        sub.batch, sub.no_cpu = 512, True
                     out["configs"][name] = bench_config(sub, R)
                 except Exception as e:        # a side line must not take the headline down with it
                     out["configs"][name] = {"error": "%s: %s" % (type(e).__name__, e)}
@@ -613,9 +615,12 @@ CONFIGS = {
     "dcmotor": ("tenscalc_amd.problems.mpc_dcmotor", "mpc_dcmotor", "dcmotor_data", 32768, "strict", 32768,
                 "mpc_dcmotor T=30 (323x323 KKT), batch=%d parameter sweep per GPU, fp64 (BASELINE.json configs[3]: the "
                 "whole 8-GPU sweep of 32768 on one GPU by default)"),
-    "quadcopter": ("tenscalc_amd.problems.mpc_quadcopter", "mpc_quadcopter", "quadcopter_data", 512, "ldsc4", 512,
+    # configs[4] is stated as batch=4096 over 8 GPUs: the largest single-GPU configuration is the whole 4096 on one GPU
+    # (16 instances per CU queued behind each other: the workgroup dispatcher hands a finished instance's CU to the next
+    # one, so the 367-iteration straggler no longer IS the batch time); `--batch 512` = one GPU's share of the 8-GPU run
+    "quadcopter": ("tenscalc_amd.problems.mpc_quadcopter", "mpc_quadcopter", "quadcopter_data", 4096, "ldsc4", 512,
                    "mpc_quadcopter T=100 (1406x1406 KKT, 67 k instructions), batch=%d per GPU, fp64 (BASELINE.json "
-                   "configs[4]: the per-GPU share of 4096 over 8 GPUs)"),
+                   "configs[4]: batch=4096; 512 = the per-GPU share over 8 GPUs)"),
 }
 
 
@@ -773,6 +778,64 @@ def bench_config(args, R):
     return out
 
 
+def _cpu_config_worker(rank, parts, sub, n, mu0, maxIter, budget_s, q):
+    """one host core of the all-cores baseline of a config: the generated-C twin over this worker's instances, repeated
+    until the budget is spent (a pass cannot be interrupted)"""
+    import numpy as np  # noqa: F401
+    from oracle.c_emitter import CpuTwin
+    tw = CpuTwin.from_parts(*parts)
+    tw.solve_batch({k: v[:1] for k, v in sub.items()}, 1, mu0=mu0, maxIter=maxIter)       # load, page in
+    t0 = time.perf_counter()
+    solved = 0
+    while True:
+        _, st, _ = tw.solve_batch(sub, n, mu0=mu0, maxIter=maxIter)
+        solved += int((st == 0).sum())
+        if time.perf_counter() - t0 >= budget_s:
+            break
+    q.put((rank, time.perf_counter() - t0, solved))
+
+
+def cpu_all_cores_config(twin, sub, n, SOLVE, per_pass_s, budget_s=4.0):
+    """the CPU path of a config on every host core of the box's share (one worker process per core, the generated C keeps
+    its state in globals): worker r solves the r-th slice of the sample, sized so that a pass takes about a second,
+    again and again for `budget_s`; aggregate = solves of all workers / slowest worker's time.  MEASURED, not the one-core
+    figure times the core count."""
+    import multiprocessing as mp
+    P = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    P = max(1, min(P, int(os.environ.get("TC_CPU_WORKERS", "16"))))
+    per = max(1, min(n // P if n >= P else 1, int(max(1.0, 1.0 / max(per_pass_s / max(n, 1), 1e-9)))))      # ~1 s per pass
+    ps, res = [], []
+    try:
+        ctx = mp.get_context("spawn")
+        q = ctx.Queue()
+        for r in range(P):
+            lo = (r * per) % max(1, n - per + 1)
+            ps.append(ctx.Process(target=_cpu_config_worker,
+                                  args=(r, twin.parts(), {k: v[lo:lo + per].copy() for k, v in sub.items()}, per,
+                                        SOLVE["mu0"], SOLVE["maxIter"], budget_s, q)))
+        for p_ in ps:
+            p_.start()
+        deadline = time.monotonic() + 120 + 4 * budget_s
+        while len(res) < P:
+            try:
+                res.append(q.get(timeout=1.0))
+            except Exception:
+                if any(p_.exitcode not in (None, 0) for p_ in ps) or time.monotonic() > deadline:
+                    return None
+    except Exception:
+        return None
+    finally:
+        for p_ in ps:
+            if p_.is_alive() and len(res) < P:
+                p_.terminate()
+        for p_ in ps:
+            p_.join(timeout=10)
+    wall = max(r[1] for r in res)
+    return {"value_all_cores": sum(r[2] for r in res) / wall, "cores_all": P,
+            "sample_all_cores": "%d worker processes, each its own %d instances of the sample over and over for %.1f s "
+                                "(slowest worker %.2f s)" % (P, per, budget_s, wall)}
+
+
 def cpu_baseline_config(spec, which, stacked, names, n, SOLVE, st, it, budget_s=8.0):
     """bounded sample of the same workload on one host core: the generated-C twin (the tape as reference-style C + the
     reference's ipmPD_CSsolver.c, gcc -O1; for the big tapes every value in the scratchbook and the group bodies cut
@@ -819,6 +882,10 @@ def cpu_baseline_config(spec, which, stacked, names, n, SOLVE, st, it, budget_s=
            "sample": "first %d instances of the benchmark batch, %s, sequential on 1 of %d host cores, %.2f s per pass"
                      % (n, how, os.cpu_count(), dt),
            "same_status_iter": bool(np.array_equal(st[:n], st2) and np.array_equal(it[:n], it2))}
+    if twin is not None and not os.environ.get("TC_BENCH_NO_ALLCORES"):
+        allc = cpu_all_cores_config(twin, sub, n, SOLVE, dt, budget_s=min(4.0, budget_s))
+        if allc:
+            res.update(allc)
     if which == "l1l2" and twin is not None:
         # the GPU class orders the KKT factorisation for a short dependency chain (1.2x the multiply-adds); a CPU would
         # keep the fill-minimising order: the same sample through the twin of THAT tape, reported beside the first

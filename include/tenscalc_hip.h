@@ -117,6 +117,13 @@ int tc_get_stats(tc_solver_t *h, double *out);
  * per dependency group executions and time of the last batched solve, averaged over its instances, written to
  * `filename` in the reference's table layout.  TC_EINVAL for classes built without stats=True. */
 int tc_profiling_view(tc_solver_t *h, const char *filename);
+/* the reference's per-iteration table of solverVerboseLevel >= 3 (lib/ipmPD_CSsolver.c:248-260 header, :305-345 exit
+ * tests, :384 mu, :422-546 regularisation, :558-577 / :632-663 step lengths, :775-863 update and mu rule; the reference
+ * prints it to the MATLAB console while it solves its ONE instance) for instance `instance` of the batch, written to
+ * `filename`: the batch is solved once more with the arguments of the last tc_solve (results unchanged) while the
+ * device loop records that instance's rows.  TC_EINVAL for classes generated with solverVerboseLevel < 3 (production
+ * classes carry no recording code), before the first solve, or for an instance outside the batch. */
+int tc_trace(tc_solver_t *h, int64_t instance, const char *filename);
 
 #ifdef __cplusplus
 }

@@ -97,6 +97,8 @@ def build_devloop(tag, defines, opt="-O1", solver="ipmPD_CSsolver"):
     with open(defs, "w") as f:
         f.write("".join("#define %s %s\n" % (k, _fmt(defines[k]))
                         for k in (EQ_DEFINE_NAMES if solver == "ipmPDeq_CSsolver" else DEFINE_NAMES)))
+        if int(defines.get("verboseLevel", 0)) >= 3 and solver != "ipmPDeq_CSsolver":     # the recorded iteration table
+            f.write("#define verboseLevel %d\n" % int(defines["verboseLevel"]))
     _run(["g++", "-w", opt, "-ffp-contract=off", "-fPIC", "-c", "-I", HERE, "-I", csrc] +
          (["-DTC_LOOP_EQ=1"] if solver == "ipmPDeq_CSsolver" else []) +
          ['-DTC_DEFINES_H="%s"' % defs, os.path.join(HERE, "devloop_glue.cpp"), "-o", obj])

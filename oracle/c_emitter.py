@@ -201,6 +201,19 @@ class CpuTwin:
         self.L = ctypes.CDLL(self.path)
         self._ct = ctypes
 
+    @classmethod
+    def from_parts(cls, path, names, sizes, nout):
+        """a twin from what a worker process needs of it (bench.py's all-cores baseline: no tape is rebuilt there)"""
+        import ctypes
+        self = cls.__new__(cls)
+        self.path, self.names, self.sizes, self.nout = path, list(names), list(sizes), int(nout)
+        self.L = ctypes.CDLL(path)
+        self._ct = ctypes
+        return self
+
+    def parts(self):
+        return self.path, list(self.names), list(self.sizes), int(self.nout)
+
     def solve_batch(self, inputs, B, mu0=1.0, maxIter=200, addEye2Hessian=(1e-9, 1e-9)):
         """inputs: {name: [B, size]} -> (out [B, nOut], status, iter)"""
         ct = self._ct

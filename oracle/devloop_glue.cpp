@@ -19,6 +19,10 @@ extern "C" {
 #define __forceinline__ inline
 struct TcCtx {
   tco_t *g;
+#if defined(verboseLevel) && verboseLevel >= 3
+  double *v3, *v3cur;   /* rows of the verbose iteration table (csrc/ipm_newton.hip.inc: TC_V3), as in the generated classes */
+  int v3n, v3max;
+#endif
 };
 
 /* trace of entry-point calls (entry indices) of the last tcdev_solve: tests/test_loop_schedule.py replays
@@ -51,6 +55,7 @@ SET(setAlphaPrimal__)
 SET(setAlphaDualEq__)
 SET(setAlphaDualIneq__)
 SET(setMu__)
+GET1(getJ__)
 GET1(getDirectionError__)
 GET1(getScale4Cost__)
 GET1(getNorminf_G__)
@@ -94,14 +99,33 @@ static inline void getHessInertia__(TcCtx &c, double *mp, double *mn) {
 #define TC_DEVICE_LOOP ipmPD_CSsolver
 #endif
 
+#if defined(verboseLevel) && verboseLevel >= 3
+#define TC_V3_HOSTROWS 4096
+static double g_v3[24 * TC_V3_HOSTROWS];
+static int g_v3n;
+/* rows the last tcdev_solve recorded (24 doubles each): tests/test_verbose_table.py */
+extern "C" int tcdev_v3_rows(double *out, int maxRows) {
+  const int n = g_v3n < maxRows ? g_v3n : maxRows;
+  for (int k = 0; k < 24 * n; k++) out[k] = g_v3[k];
+  return g_v3n;
+}
+#endif
+
 extern "C" void tcdev_solve(tco_t *g, double mu0, int maxIter, double ae0, double ae1, int32_t *status,
                             int32_t *iter) {
+#if defined(verboseLevel) && verboseLevel >= 3
+  TcCtx c = {g, g_v3, nullptr, 0, TC_V3_HOSTROWS};
+#else
   TcCtx c = {g};
+#endif
   int st = 0, it = 0;
   g_ntrace = 0;
   TC_DEVICE_LOOP(c, mu0, maxIter, ae0, ae1, &st, &it);
   *status = st;
   *iter = it;
+#if defined(verboseLevel) && verboseLevel >= 3
+  g_v3n = c.v3n;
+#endif
 }
 
 extern "C" int tcdev_trace(int32_t *out, int max) {

@@ -35,6 +35,9 @@ def build(st):
         if k == "F":          # F=-amdgpu-sched-strategy:max-ilp -> -mllvm -amdgpu-sched-strategy=max-ilp
             kw["extra_flags"] = tuple(kw.get("extra_flags", ())) + ("-mllvm", v.replace(":", "="))
             continue
+        if k == "T":          # T=none -> without the variant's optional flags; T=-amdgpu-sched-strategy:max-ilp -> that one instead
+            kw["try_flags"] = () if v == "none" else ("-mllvm", v.replace(":", "="))
+            continue
         if k == "D":          # D=NAME:VALUE -> -DNAME=VALUE (diagnostic builds, e.g. D=TCL_DUP_CHAIN:2)
             kw["extra_flags"] = tuple(kw.get("extra_flags", ())) + ("-D" + v.replace(":", "="),)
             continue

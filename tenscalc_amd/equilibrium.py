@@ -258,6 +258,12 @@ def ipmPDeqlat_CS(code, *, u, d, x, f, g, Fu, Fd, Gu, Gd, H, P1lambda, P1nu, P1x
                 Mehrotra = rdivide(times(F_z * dZ_a, dLambda_a), lam)
                 b_s = _vcat(*(grads + ([-G] if nG > 0 else []) + [-F - Mehrotra + rdivide(muOnes, lam)]))
                 if useLDL:
+                    # DELIBERATE DEVIATION from ipmPDeqlat_CS.m:702-707: the reference rebuilds b_s here WITHOUT the WW'
+                    # factor it applied at :646-648, i.e. it solves (WW'WW) dx = b_s with an un-symmetrised right-hand side
+                    # whenever skipAffine=false meets useLDL=true.  The small-matrix branch above follows the reference's
+                    # formula to the letter (:419-421 then :473-479, the same slip) and, like the reference's solver, then
+                    # walks into maxIter; this branch keeps the product, so the option pair is usable with the default
+                    # (large) matrix.  tests/test_equilibrium.py::test_predictor_step_on_the_symmetrised_system, DESIGN.md 7.
                     b_s = transpose(WWraw) * b_s
             rho = rdivide(tprod(newF_a, (-1,), newLambda_a, (-1,)), gap)
             code.declareGet([maxAlphaPrimal_a, maxAlphaDualIneq_a], "getMaxAlphas_a__")

@@ -81,6 +81,11 @@ def _define_block(spec):
         if k in spec.defines:
             w.append(f"#define {k} {_lit(spec.defines[k])}\n")
     w.append(f"#define TC_SOLVER_SYMBOL {_solver_of(spec)}\n")
+    if int(spec.defines.get("verboseLevel", 0)) >= 3:
+        # solverVerboseLevel >= 3 (cmex2optimizeCS.m:331 passes it to the template): the per-iteration table of
+        # ipmPD_CSsolver.c:248-345,775-863 is recorded for one instance (csrc/ipm_newton.hip.inc: TC_V3) and written by
+        # tc_trace.  Lower levels print nothing per iteration and generate nothing here.
+        w.append(f"#define verboseLevel {int(spec.defines['verboseLevel'])}\n#define TC_VERBOSE3 1\n#define TC_V3_MAXROWS 4096\n")
     return "".join(w)
 
 
@@ -1099,6 +1104,9 @@ def emit_class(spec, fp_contract="fast", block=64, stats=False, roll=True, min_w
     w.append(f'#define TC_CLASSNAME "{cls}"\n#define TC_BLOCK {int(block)}\n#define TC_P {int(lanes)}\n'
              f"#define TC_G (TC_BLOCK / TC_P)\n#define TC_NDIST {L.nDist}\n")
     lb = f"__launch_bounds__(TC_BLOCK, {int(min_waves)})" if min_waves else "__launch_bounds__(TC_BLOCK)"
+    if os.environ.get("TC_WPE"):        # tuning aid (hashed into the build key): "1,1" -> amdgpu_waves_per_eu(1, 1)
+        wpe_ = os.environ["TC_WPE"].split("-")
+        lb += f" __attribute__((amdgpu_waves_per_eu({wpe_[0]}, {wpe_[-1]})))"
     w.append(f"#define TC_LAUNCH_BOUNDS {lb}\n")
     if stats:       # stats="phases": only the per-phase counters of the Newton loop (8 registers; the per-group
         # stats="trace": lane 0 of block 0 writes (tag, s_memtime) pairs to the dbg buffer at every group evaluation and
@@ -1176,7 +1184,9 @@ def emit_class(spec, fp_contract="fast", block=64, stats=False, roll=True, min_w
              "  const __attribute__((address_space(1))) char *Sdb;\n  unsigned sdo8, sdB8;\n"
              "  unsigned long long st[TC_NSTW];\n" + (f"  double rv[{nrv}];\n" if nrv else "") + dmembers +
              "#if defined(TC_STATS) && TC_STATS == 3\n  __attribute__((address_space(1))) double *trp, *trpEnd;   // trace cursor, end of the dbg buffer (stamps stop there)\n"
-             "#elif defined(TC_STATS)\n  int nMinF;\n  long long cyc[TC_NGROUPS];\n  int cnt[TC_NGROUPS];\n  long long ph[8], tph;\n#endif\n};\n"
+             "#elif defined(TC_STATS)\n  int nMinF;\n  long long cyc[TC_NGROUPS];\n  int cnt[TC_NGROUPS];\n  long long ph[8], tph;\n#endif\n"
+             "#ifdef TC_VERBOSE3\n  double *v3, *v3cur;   // rows of the verbose table (ipm_newton.hip.inc: TC_V3); null on all but the traced instance\n"
+             "  int v3n, v3max;\n#endif\n};\n"
              # input reads are clamped to the input block: every index the emitter prints is in range (constants
              # fold away), the clamp is the backstop for a lane of a split loop that should have been masked
              "#define SX(k) (S[(long)((k) < TC_NEXT ? (k) : (TC_NEXT > 0 ? TC_NEXT - 1 : 0)) * B])\n"
@@ -1434,7 +1444,10 @@ def emit_class(spec, fp_contract="fast", block=64, stats=False, roll=True, min_w
                 "  if (c.trp) { c.trp[0] = 1000.0; c.trp[1] = (double)clock64(); c.trp += 2; }\n"
                 "#elif defined(TC_STATS)\n  c.nMinF = 0;\n  for (int k = 0; k < TC_NGROUPS; k++) { c.cyc[k] = 0; c.cnt[k] = 0; }\n"
                 "  for (int k = 0; k < 8; k++) c.ph[k] = 0;\n"
-                "  const long long tstart_ = clock64();\n  c.tph = tstart_;\n#endif\n")
+                "  const long long tstart_ = clock64();\n  c.tph = tstart_;\n#endif\n"
+                "#ifdef TC_VERBOSE3   // dbg[0] = the instance whose iteration table is recorded, rows from dbg + 8 (tc_trace)\n"
+                "  c.v3 = nullptr; c.v3cur = nullptr; c.v3n = 0; c.v3max = 0;\n"
+                "  if (dbg && c.lane == 0 && tid == (long)dbg[0]) { c.v3 = dbg + 8; c.v3max = TC_V3_MAXROWS; }\n#endif\n")
     prologue += ("  c.Sd = (tc_glob)(Sd + tid * TC_P + c.lane);\n  c.sdB = B * TC_P;\n"
                  "  c.Sdb = (const __attribute__((address_space(1))) char *)Sd;\n"
                  "  c.sdo8 = (unsigned)((tid * TC_P + c.lane) * 8);\n  c.sdB8 = (unsigned)(B * TC_P * 8);\n")
@@ -1492,6 +1505,7 @@ def emit_class(spec, fp_contract="fast", block=64, stats=False, roll=True, min_w
             out_meta.append((o["name"], o["size"], n_, off))
             off += n_
     w.append("  status[tid] = st;\n  iter[tid] = it;\n"
+             "#ifdef TC_VERBOSE3\n  if (c.v3) { dbg[1] = (double)c.v3n; dbg[2] = (double)st; dbg[3] = (double)it; }\n#endif\n"
              "#if defined(TC_STATS) && TC_STATS == 3\n  if (c.trp) { c.trp[0] = 1001.0; c.trp[1] = (double)clock64(); c.trp[2] = 0.0; }\n"
              "#elif defined(TC_STATS)\n  if (dbg) {\n    for (int k = 0; k < TC_NGROUPS; k++) {\n"
              "      dbg[(long)k * B + tid] = (double)c.cyc[k];\n      dbg[(long)(TC_NGROUPS + k) * B + tid] = (double)c.cnt[k];\n    }\n"
@@ -1504,7 +1518,7 @@ def emit_class(spec, fp_contract="fast", block=64, stats=False, roll=True, min_w
     w.append("extern \"C\" __global__ void __launch_bounds__(TC_BLOCK)\n"
              "tc_probe_kernel(const double *__restrict__ S, const double *__restrict__ Sd, double *__restrict__ out,\n"
              "                int which, double mu0, double ae0, double ae1, long B, double *__restrict__ Mg) {\n"
-             "#if defined(TC_STATS) && TC_STATS == 3\n  double *dbg = nullptr;\n#endif\n" + prologue
+             "#if (defined(TC_STATS) && TC_STATS == 3) || defined(TC_VERBOSE3)\n  double *dbg = nullptr;\n#endif\n" + prologue
              + (("#if setAddEye2Hessian != 0\n  setAddEye2Hessian1__(c, &ae0);\n  setAddEye2Hessian2__(c, &ae1);\n#endif\n"
                  "  initPrimal__(c);\n#if scaleCost != 0\n  scaleCost__(c);\n#endif\n"
                  "#if nF > 0\n#if scaleInequalities != 0\n  scaleIneq__(c);\n#endif\n  setMu__(c, &mu0);\n  initDualIneq__(c);\n#endif\n"
@@ -1603,9 +1617,13 @@ def _ldsc_functions(cs, W, chunk=96, depth=12, trace=False):
     instance at depth 4: 566 / 369 / 294 / 278; 4 wavefronts at depth 2 / 4 / 8 / 12 / 16: 323 / 294 / 276 / 275 / 277.
     On the final round-4 stream (steps a third as long): depth 6 / 8 / 12 / 16 / 20: 165.7 / 156.5 / 152.0 / 153.5 / 152.0 -> 12."""
     # functions stay at `chunk` = 96 records: a build with 384 per function (mpc_quadcopter, W = 4) took a GPU memory
-    # access fault on its first launch -- 20 k instructions per function, i.e. branch distances beyond the 16-bit
-    # offsets; never investigated further, never run again
+    # access fault on its first launch in round 4.  Round 5 (scripts/ldsc_chunk_probe.py, offline): kernel descriptor,
+    # scratch (196 vs 204 B) and registers of the two builds are the same; what differs is that functions beyond 32 767
+    # dwords make LLVM RELAX branches into s_getpc / s_add / s_setpc sequences on a scavenged SGPR pair (36 of them in
+    # the 35 k-instruction function, none in any 96-record build).  build_class therefore checks the CONDITION -- no
+    # function of the walk within reach of that limit (_largest_function) -- instead of trusting the record count.
     depth = int(os.environ.get("TC_LDSC_DEPTH", depth))          # tuning aid (hashed into the build key)
+    chunk = int(os.environ.get("TC_LDSC_CHUNK", chunk))          # diagnostic (ditto): scripts/ldsc_chunk_probe.py
     hd = np.asarray(cs["headers"], dtype=np.int64).reshape(-1, 8)
     table = cs["table"]
     nrid = len(table) // (2 * W)
@@ -1708,7 +1726,7 @@ def _ldsc_functions(cs, W, chunk=96, depth=12, trace=False):
     return "".join(w)
 
 
-def emit_class_ldsm(spec, waves=4, stats=False, lds_slots=20000, fuse_chain=True, compiled=False):
+def emit_class_ldsm(spec, waves=4, stats=False, lds_slots=20000, fuse_chain=True, compiled=False, lds_stage=0):
     """body="ldsm": ONE instance per workgroup of `waves` wavefronts, hot state in LDS, the tape as data whose
     records give every lane a different scalar instruction (csrc/tc_ldsm.hip.inc, ldsm_schedule.py)."""
     from . import ldsm_schedule as lsch
@@ -1723,7 +1741,7 @@ def emit_class_ldsm(spec, waves=4, stats=False, lds_slots=20000, fuse_chain=True
         T = lsch.fused_tape(T, spec.defines)
     cls = spec.classname
     W = int(waves)
-    cs = lsch.class_stream(T, cls, spec.defines, W=W, lds_slots=lds_slots)
+    cs = lsch.class_stream(T, cls, spec.defines, W=W, lds_slots=lds_slots, stage=lds_stage)
     L = cs["lowering"]
     addr = cs["addr"]
     nW = max(1, (T.nGroups + 63) // 64)
@@ -2025,6 +2043,26 @@ def class_header(spec):
     return s
 
 
+def _largest_function(so, prefix=""):
+    """(name, bytes) of the largest device function of a class library whose name contains `prefix` (code-object symbol
+    table; ("", 0) when there is none)"""
+    import re
+    import tempfile
+    llvm = os.environ.get("TC_LLVM_BIN", "/opt/rocm/lib/llvm/bin")
+    with tempfile.TemporaryDirectory() as d:
+        fb, co = os.path.join(d, "k.fatbin"), os.path.join(d, "k.co")
+        subprocess.run([os.path.join(llvm, "llvm-objcopy"), "-O", "binary", "--only-section=.hip_fatbin", so, fb], check=True)
+        subprocess.run([os.path.join(llvm, "clang-offload-bundler"), "--unbundle", "--type=o", "--input=" + fb,
+                        "--targets=hipv4-amdgcn-amd-amdhsa--gfx950", "--output=" + co], check=True, capture_output=True)
+        txt = subprocess.run([os.path.join(llvm, "llvm-readelf"), "-s", "-W", co], capture_output=True, text=True, check=True).stdout
+    best = ("", 0)
+    for ln in txt.splitlines():
+        m = re.match(r"\s*\d+:\s+[0-9a-f]+\s+(\d+)\s+FUNC\s+\S+\s+\S+\s+\S+\s+(\S+)", ln)
+        if m and prefix in m.group(2) and int(m.group(1)) > best[1]:
+            best = (m.group(2), int(m.group(1)))
+    return best
+
+
 def _deps_of(src):
     """the csrc / include files a class source reads, found by following its #include "..." lines (sorted)"""
     import re
@@ -2047,16 +2085,21 @@ def build_class(spec, fp_contract="fast", arch="gfx950", opt="-O3", block=64, fo
                 recip=False, fast_div=False, inline_max=0, reg_budget=150, scratch="auto", body="code",
                 waves=1, fuse=False, static_clean=False, forward=False, rcache=0, lds_state=0, share=False,
                 branch_free_tails=True, exact=False, stg_blocks=0, lds_slots=20000, ilp=False, fw_window=0, sched_every=0,
-                try_flags=(), refresh_outputs=False, compiled=False):
+                try_flags=(), refresh_outputs=False, compiled=False, lds_stage=0, key_only=False):
     """Emit <cls>.hip (+ <cls>.h, <cls>.tape) and compile lib<cls>.so with hipcc for gfx950.
     Mirrors the createGateway/compile step of cmex2optimizeCS.m:403-417.
 
     try_flags: compiler flags worth having but not worth failing for (LLVM's experimental scheduling strategies crash
-    the compiler on some classes): tried first, dropped if hipcc fails with them; lib<cls>.flags records what was used."""
+    the compiler on some classes): tried first, dropped if hipcc fails with them; lib<cls>.flags records what was used.
+
+    key_only: nothing is written or compiled; returns (quick key, source digest) as recorded in <cls><tag>.key /
+    <cls><tag>.stamp next to a library -- tests/test_class_digests.py recomputes them from the tracked sources for the
+    shipped (git-ignored) libraries.  key_only="quick": the quick key alone, without emitting the source."""
     from .tapeio import save_tape, tape_records, _rec
     cls = spec.classname
     outdir = outdir or os.path.join(spec.folder, f"@{cls}")
-    os.makedirs(outdir, exist_ok=True)
+    if not key_only:
+        os.makedirs(outdir, exist_ok=True)
     suffix = f"_{tag}" if tag else ""
     # Quick key: the tape, the options and the generator's own sources.  If it matches the one recorded with the
     # library the source need not be emitted again just to be hashed -- lowering mpc_dcmotor for 32 lanes with slot
@@ -2067,7 +2110,7 @@ def build_class(spec, fp_contract="fast", arch="gfx950", opt="-O3", block=64, fo
     kq.update(repr((cls, sorted(spec.defines.items()), [(n, tuple(sz)) for n, sz in spec.outputs], fp_contract, arch, opt, block,
                     stats, tag, tuple(extra_flags), roll, min_waves, lanes, recip, fast_div, inline_max, reg_budget, scratch,
                     body, waves, fuse, static_clean, forward, rcache, lds_state, share, branch_free_tails, exact, stg_blocks,
-                    lds_slots, ilp, fw_window, sched_every, tuple(try_flags), refresh_outputs, compiled, os.environ.get("TC_LDS_PAD_SLOTS", ""), os.environ.get("TC_STG_BATCH", ""), os.environ.get("TC_LDSM_FUSE", ""), os.environ.get("TC_INTERP_FUSE", ""), os.environ.get("TC_LDSM_LOOP_MERGE", ""), os.environ.get("TC_LDSC_DEPTH", ""), os.environ.get("TC_LDSM_PACK_LOCALS", ""), os.environ.get("TC_LDSM_ROW_SKEW", ""), os.environ.get("TC_LDSM_LATE_LAST", ""), os.environ.get("TC_LDSM_PAD_PRODUCTS", ""), os.environ.get("TC_LDSM_MERGE_PRODUCTS", ""), os.environ.get("TC_LDSM_COLD_RANK", ""), os.environ.get("TC_LDSC_TWO_PHASE", ""), os.environ.get("TC_LDSC_SPLIT_HBM", ""), os.environ.get("TC_LDSC_SCHEDB", ""), os.environ.get("TC_LDSC_BYTES", ""), os.environ.get("TC_LDSC_WPE", ""), os.environ.get("TC_LDSM_STAGE", ""),
+                    lds_slots, ilp, fw_window, sched_every, tuple(try_flags), refresh_outputs, compiled, lds_stage, os.environ.get("TC_LDS_PAD_SLOTS", ""), os.environ.get("TC_STG_BATCH", ""), os.environ.get("TC_LDSM_FUSE", ""), os.environ.get("TC_INTERP_FUSE", ""), os.environ.get("TC_LDSM_LOOP_MERGE", ""), os.environ.get("TC_LDSC_DEPTH", ""), os.environ.get("TC_LDSM_PACK_LOCALS", ""), os.environ.get("TC_LDSM_ROW_SKEW", ""), os.environ.get("TC_LDSM_LATE_LAST", ""), os.environ.get("TC_LDSM_PAD_PRODUCTS", ""), os.environ.get("TC_LDSM_MERGE_PRODUCTS", ""), os.environ.get("TC_LDSM_COLD_RANK", ""), os.environ.get("TC_LDSC_TWO_PHASE", ""), os.environ.get("TC_LDSC_SPLIT_HBM", ""), os.environ.get("TC_LDSC_SCHEDB", ""), os.environ.get("TC_LDSC_BYTES", ""), os.environ.get("TC_LDSC_WPE", ""), os.environ.get("TC_LDSM_STAGE", ""), os.environ.get("TC_LDSC_CHUNK", ""), os.environ.get("TC_WPE", ""),
                     os.environ.get("TC_SWEEP_UNROLL", ""))).encode())
     for f_ in sorted(os.listdir(HERE)):
         if f_.endswith(".py"):
@@ -2077,15 +2120,17 @@ def build_class(spec, fp_contract="fast", arch="gfx950", opt="-O3", block=64, fo
             if f_.endswith((".inc", ".h")):
                 kq.update(open(os.path.join(d_, f_), "rb").read())
     quick = kq.hexdigest()
+    if key_only == "quick":
+        return quick
     so_ = os.path.join(outdir, f"lib{cls}{suffix}.so")
     qfile = os.path.join(outdir, f"{cls}{suffix}.key")
-    if not force and os.path.exists(so_) and os.path.exists(qfile) and open(qfile).read().strip() == quick:
+    if not key_only and not force and os.path.exists(so_) and os.path.exists(qfile) and open(qfile).read().strip() == quick:
         return so_
     if body == "ldsm":
         if fp_contract != "off":
             raise ValueError("body='ldsm' is a bit-exact back-end: fp_contract='off'")
         src, L = emit_class_ldsm(spec, waves=waves, stats=stats, lds_slots=lds_slots,      # TC_LDSM_FUSE=0: no fused walk
-                                 compiled=bool(compiled))
+                                 compiled=bool(compiled), lds_stage=lds_stage)
     else:
       src, L = emit_class(spec, fp_contract=fp_contract, block=block, stats=stats, roll=roll,
                         min_waves=min_waves, lanes=lanes, recip=recip, fast_div=fast_div, inline_max=inline_max,
@@ -2104,6 +2149,8 @@ def build_class(spec, fp_contract="fast", arch="gfx950", opt="-O3", block=64, fo
         h.update(open(d, "rb").read())
     stamp = os.path.join(outdir, f"{cls}{suffix}.stamp")
     digest = h.hexdigest()
+    if key_only:
+        return quick, digest
     if (not force and os.path.exists(so) and os.path.exists(stamp)
             and open(stamp).read().strip() == digest):
         with open(qfile, "w") as f:
@@ -2126,6 +2173,17 @@ def build_class(spec, fp_contract="fast", arch="gfx950", opt="-O3", block=64, fo
         r = subprocess.run(cmd, capture_output=True, text=True)
     if r.returncode:
         raise RuntimeError(f"hipcc failed for class {cls}:\n{' '.join(cmd)}\n{r.stdout}\n{r.stderr}")
+    if compiled:
+        # The compiled walk's functions must stay below the reach of a 16-bit branch offset (32 767 dwords = 128 KB):
+        # beyond it LLVM relaxes branches into s_getpc / s_add / s_setpc sequences on a scavenged SGPR pair -- the one
+        # difference between the 384-record build that took a GPU memory-access fault in round 4 and the 96-record builds
+        # that never did (scripts/ldsc_chunk_probe.py: 36 relaxed branches in a 35 k-instruction function against none).
+        # The cut is by records (chunk = 96: 55 KB for mpc_quadcopter); THIS is the condition it stands for.
+        big = _largest_function(so, "tcc_r")
+        if big[1] >= 120 * 1024:
+            os.remove(so)
+            raise RuntimeError(f"compiled LDS walk of {cls}: function {big[0]} is {big[1]} bytes -- beyond the reach of a "
+                               "16-bit branch (128 KB); lower the records per function (hip_emitter._ldsc_functions chunk)")
     with open(os.path.join(outdir, f"lib{cls}{suffix}.flags"), "w") as f:
         f.write(" ".join(used) + "\n")
     with open(stamp, "w") as f:

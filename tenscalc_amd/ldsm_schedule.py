@@ -1011,9 +1011,9 @@ def copy_records(words, headers, pairs, nLds, W=1):
     return rg
 
 
-def class_stream(T, classname, defines, W=1, lds_slots=20000, hoist=True, nested=True, split=True):
+def class_stream(T, classname, defines, W=1, lds_slots=20000, hoist=True, nested=True, split=True, stage=0):
     """everything the device walk needs for one class"""
-    sl = assign_slots(T, defines, lds_slots)
+    sl = assign_slots(T, defines, lds_slots, stage=int(stage) or STAGE)
     addr, nLds = sl["addr"], sl["nLds"]
     st = build_stream(T, addr, nLds, W, stage_base=sl["stage_base"], nStage=sl["nStage"], hoist=hoist,
                       pads=(sl["negzero"], sl["posinf"], sl["neginf"]), one=sl["one"], nested=nested, split=split)

@@ -468,6 +468,8 @@ class Lowering:
                 req.append((blk, any(x[0] for x in lives), min(x[1] for x in lives), max(x[2] for x in lives)))
 
         self._last_req = req                 # diagnostics (scripts, tests): (block, init, first, last) per block
+        if getattr(self, "_req_only", False):    # diagnostics: life times wanted, no packing
+            return 0
 
         def pack(order):
             placed, where_of, size = [], {}, 0           # placed: (first slot, size, init, a, b)

@@ -51,6 +51,11 @@ def mpc_dcmotor(T=30, classname="tmp_mpc_dcmotor", **options):
     uWarm = tc.min2(uWarm, tc.repmat(max_u - .05 * (max_u - min_u), (1, T - 1)))
     outs = dict(J=J, Jx2=Jx2, Ju2=Ju2, t=tc.Tconstant(np.arange(T, dtype=float)) * Ts, u=u, x=x, ref=ref,
                 xWarm=tc.full(xWarm), uWarm=tc.full(uWarm))
+    # Elimination order: greedy minimum degree.  Round 5 measured multiple elimination with tolerance 1
+    # (`ldlOrder=("mmd", 1)`: 440 -> 246 dependent levels per Newton iteration; LDS machine 34.0 -> 21.5 ms per 32768, tile
+    # machine 23.0 -> 20.9, profiles/r05_dcmotor_orders.log) and did not adopt it: on one of three seeds the iterate after
+    # three Newton steps leaves the tape-independent dense IPM by 3e-2 (tests/test_tape_vs_dense_ipm.py) -- the equality
+    # duals' pivots are where that order loses digits (DESIGN.md 7 "numerical finding").
     return cmex2optimizeCS(classname=classname, objective=J, optimizationVariables=[u, x],
                            constraints=dynamics + constraints, outputExpressions=list(outs.values()),
                            outputNames=list(outs.keys()),

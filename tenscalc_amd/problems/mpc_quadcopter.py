@@ -49,6 +49,15 @@ def mpc_quadcopter(T=100, classname="tmp_quadcopter", **options):
     J = Jp2 + lambda_v * Jv2 + lambda_thrust * Jthrust
     outs = dict(J=J, Jp2=Jp2, Jv2=Jv2, Jthrust=Jthrust, t=tc.Tconstant(np.arange(T, dtype=float)) * Ts, u=u,
                 m_thrust=m_thrust, p=p, v=v, a=a, R_ib1=R_ib1, R_ib2=R_ib2, R_ib3=R_ib3, positive2=positive2)
+    # Elimination order of the KKT factorisations (the reference calls symamd, which is not available: DESIGN.md 7).
+    # Round 5: multiple elimination with degree tolerance 0 (independent sets of minimum-degree nodes per round): the
+    # chain through factor + solves is 2.3x shorter at 1.03x the fill, and the pivots are those of the greedy order in
+    # quality (smallest pivot 5.6e-6, solve error 1.2e-6 on the KKT matrix at the initial point).  Round 3 kept
+    # the greedy order because a batch of 512 ends with its slowest instance and this order moves that instance from 367
+    # to 563 iterations; at configs[4]'s stated batch of 4096 on one GPU the CUs are handed the next instance when one
+    # finishes, so what counts is the time per Newton iteration: 614 -> 522 ms per 4096 (profiles/r05_quadcopter_orders.log).
+    # The tape-independent dense NLP pin holds unchanged (tests/test_tape_vs_dense_ipm.py: same 26 iterations, 1e-10).
+    options.setdefault("ldlOrder", ("mmd", 0))
     return cmex2optimizeCS(classname=classname, objective=J, optimizationVariables=[p, u, positive2],
                            constraints=dynamics + constraints, outputExpressions=list(outs.values()),
                            outputNames=list(outs.keys()),

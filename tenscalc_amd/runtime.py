@@ -77,6 +77,7 @@ def _bind(path):
     L.tc_stats_rows.restype = c.c_int64
     L.tc_get_stats.argtypes = [c.c_void_p, _dp]
     L.tc_profiling_view.argtypes = [c.c_void_p, c.c_char_p]
+    L.tc_trace.argtypes = [c.c_void_p, c.c_int64, c.c_char_p]
     L.tc_probe_numel.restype = c.c_int64
     L.tc_probe_numel.argtypes = [c.c_char_p]
     return L
@@ -225,6 +226,11 @@ class HipSolver:
         """the reference class's profilingView(obj, filename) (writeCprofiling.c:8-83): per dependency group executions and
         time of the last solve, averaged over the batch; classes built with stats=True only"""
         self._check(self._L.tc_profiling_view(self._h, os.fsencode(filename)))
+
+    def trace(self, instance, filename):
+        """the reference's solverVerboseLevel >= 3 iteration table (ipmPD_CSsolver.c:248-345,775-863) of ONE instance of the
+        last batched solve, written to `filename`; classes generated with solverVerboseLevel >= 3 only"""
+        self._check(self._L.tc_trace(self._h, int(instance), os.fsencode(filename)))
 
     def probe(self, get_name, mu0=1.0, addEye2Hessian=(1e-9, 1e-9)):
         """evaluate a tape get entry point after the solver's initialisation sequence -> [B, numel]"""

@@ -154,6 +154,30 @@ def test_matrix_game_value_against_linear_programming(native_built, tmp_path):
         assert (A.T @ u).max() <= lp.fun + 1e-3 and (A @ d).min() >= lp.fun - 1e-3     # neither player can improve
 
 
+def test_predictor_step_on_the_symmetrised_system(native_built, tmp_path):
+    """skipAffine=false together with useLDL=true: the reference rebuilds the combined right-hand side after the predictor
+    step without the WW' factor of the symmetrised system (ipmPDeqlat_CS.m:646-648 vs :702-707 large matrix; :419-421 vs
+    :473-479 small matrix).  Here the LARGE matrix keeps the factor (a documented deviation, equilibrium.py): the solver
+    converges to the closed form, as with LU; the SMALL matrix follows the reference's formula and, like it, does not."""
+    from tenscalc_amd.problems.tc_games import GAMES, SOLVE_ARGS, game_data
+    from tenscalc_amd.tapeio import save_tape
+    from oracle.tc_oracle import Oracle
+    N = GAMES["qs"][2]["N"]
+    sol = {}
+    for tag, opt in (("lu", dict(skipAffine=False)), ("ldl", dict(skipAffine=False, useLDL=True)),
+                     ("ldl_small", dict(skipAffine=False, useLDL=True, smallerNewtonMatrix=True))):
+        spec = _spec("qs", **opt)
+        tape = str(tmp_path / (tag + ".tape"))
+        save_tape(spec.tape, tape)
+        o = Oracle(tape)
+        sol[tag] = [_solve(o, spec, game_data("qs", 100 + seed), SOLVE_ARGS) for seed in range(4)]
+    for (st, it, out), (st2, it2, out2) in zip(sol["lu"], sol["ldl"]):
+        assert st == 0 and st2 == 0 and abs(it - it2) <= 1
+        assert np.abs(out2[:N] - 1).max() <= 1e-4 and np.abs(out2[N:2 * N] + 1 / 9).max() <= 1e-4
+        assert np.abs(out - out2).max() <= 1e-5
+    assert all(st & 8 for st, _, _ in sol["ldl_small"])          # the reference's formula: maxIter, large gradient
+
+
 @pytest.mark.parametrize("name", ["qs", "qss"])
 def test_quadratic_saddle_point_closed_form(native_built, tmp_path, name):
     """Ju = |u+d-2|^2 - 10|d|^2 on the box [-1,1]^N: player 1 sits at u = 1, player 2's stationarity
