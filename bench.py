@@ -447,6 +447,8 @@ def bench_sls(args, R):
                          # reported beside the HBM fraction the north star asks for
                          "fp64_valu": None if R.standin else tape_flops(spec, it, B, kavg)},
         }
+        if out["roofline"]["fp64_valu"]:
+            out["roofline"]["lane_redundancy"] = lane_redundancy(args.variant, B, out["roofline"]["fp64_valu"]["flops_per_solve"])
         if sustained is not None:
             out["sustained_ms_per_step"] = sustained
             out["sustained_value"] = float((ST == 0).sum().item()) / (sustained * 1e-3)
@@ -495,6 +497,18 @@ def tape_flops(spec, it, B, kernel_s):
     tf = per_solve * B / kernel_s / 1e12
     return {"flops_per_solve": per_solve, "achieved": tf, "peak": FP64_VALU_PEAK_TFLOPS, "unit": "TFLOP/s",
             "frac": tf / FP64_VALU_PEAK_TFLOPS}
+
+
+def lane_redundancy(variant, B, flops_per_solve):
+    """lane-operations the kernel issues per useful tape operation: SQ_INSTS_VALU (wave-level VALU instructions per launch,
+    from the committed PMC pass) x 64 lanes / (tape flops per solve x B).  sls / w8x: 3.5 -- the sequential core of an
+    instance is computed redundantly by its 8 lanes.  None without a counter run for this variant and batch."""
+    try:
+        with open(os.path.join(ROOT, "profiles", "traffic.json")) as f:
+            e = json.load(f).get("%s_B%d" % (variant, B))
+        return e["sq_insts_valu"] * 64.0 / (flops_per_solve * B) if e and e.get("sq_insts_valu") else None
+    except (OSError, ValueError, KeyError, ZeroDivisionError):
+        return None
 
 
 def measured_traffic(variant, B):

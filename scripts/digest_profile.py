@@ -56,10 +56,12 @@ def main(out, rnd, var):
     tj = os.path.join(dst, "traffic.json")
     t = json.load(open(tj)) if os.path.exists(tj) else {}
     if traffic is not None:
-        B = {"quadcopter": 512, "l1l2": 16384, "dcmotor": 32768}.get(var.split("_")[0], 65536)
+        B = {"quadcopter": 4096, "l1l2": 16384, "dcmotor": 32768}.get(var.split("_")[0], 65536)
         B = int(os.environ.get("TC_PROFILE_BATCH", "0")) or B
         t["%s_B%d" % (var, B)] = {"hbm_bytes_per_launch": traffic, "fetch_size_kib": pm["FETCH_SIZE"],
                                 "write_size_kib": pm["WRITE_SIZE"], "kernel_avg_ns": kavg, "round": rnd}
+        if "SQ_INSTS_VALU" in pm:       # wave-level VALU instructions per launch: bench.py's lane-redundancy ratio
+            t["%s_B%d" % (var, B)]["sq_insts_valu"] = pm["SQ_INSTS_VALU"]
     json.dump(t, open(tj, "w"), indent=1)
     print("\n".join(lines[-14:]))
 
