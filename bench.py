@@ -626,7 +626,7 @@ CONFIGS = {
     # name: (module, builder, data fn, instances per GPU, default variant, CPU sample, workload label)
     "l1l2": ("tenscalc_amd.problems.l1l2", "l1l2", "l1l2_data", 16384, "interp8", 2048,
              "l1l2estimationCS N=200 (1792x1792 KKT, 54 k instructions), batch=%d per GPU, fp64 (BASELINE.json configs[2])"),
-    "dcmotor": ("tenscalc_amd.problems.mpc_dcmotor", "mpc_dcmotor", "dcmotor_data", 32768, "strict", 32768,
+    "dcmotor": ("tenscalc_amd.problems.mpc_dcmotor", "mpc_dcmotor", "dcmotor_data", 32768, "ldscs", 32768,
                 "mpc_dcmotor T=30 (323x323 KKT), batch=%d parameter sweep per GPU, fp64 (BASELINE.json configs[3]: the "
                 "whole 8-GPU sweep of 32768 on one GPU by default)"),
     # configs[4] is stated as batch=4096 over 8 GPUs: the largest single-GPU configuration is the whole 4096 on one GPU
@@ -664,8 +664,9 @@ def bench_config(args, R):
         B = Bmax = args.batch or B0
         lo = rank * B
     variant = args.variant or var0                       # any key of __graft_entry__.VARIANT_KW (interp8, ldsm4, strict, ...)
-    if args.config == "dcmotor" and not args.variant and 0 < Bmax <= 8192:
-        variant = "w32x"      # one GPU's share of the 8-GPU sweep: the wave-cooperative lowering (LDS-resident state) wins
+    # (mpc_dcmotor: the compiled LDS walk with four instances resident per CU is the fastest bit-exact back-end at both the
+    # whole sweep on one GPU -- 21.2 ms against 24.7 `strict`, 21.8 `interp4` -- and one GPU's share of it -- 3.1 ms per 4096
+    # against 5.3 `w32x`: profiles/r05_dcmotor_variants.log)
     spec = getattr(mod, mk)(folder=g.GENERATED)
     kw = dict(g.VARIANT_KW[variant])
     if not standin:

@@ -1,6 +1,6 @@
 """Tuning aid for the LDS-resident back-ends at full batch: residents per CU against per-solve latency.
    python scripts/lds_budget_sweep.py build|run <dcmotor|l1l2|quad> <variant> <B> <order:stage:lds_slots> ...
-order = mindeg | mmdK | depthW (scripts/order_ab.py), stage = staging slots (TC_LDSM_STAGE), lds_slots = LDS budget in doubles
+order = mindeg | mmdK | depthW (scripts/order_ab.py), optional 4th field "fine" (TC_FINE_LIVES), stage = staging slots (TC_LDSM_STAGE), lds_slots = LDS budget in doubles
 (160 KB per CU = 20 480 doubles: 5 120 -> 4 instances per CU, 4 096 -> 5, 3 413 -> 6, 2 925 -> 7, 2 560 -> 8)."""
 import os
 import sys
@@ -30,11 +30,13 @@ def order(nm):
 
 def build(cfg):
     from tenscalc_amd import tcalculus as tc
-    o, stage, slots = cfg.split(":")
+    o, stage, slots, *rest = cfg.split(":")
     os.environ["TC_LDSM_STAGE"] = stage
+    from tenscalc_amd.lowering import Lowering
+    Lowering.FINE_LIVES = bool(rest and rest[0] == "fine")       # finer life times of the exported values
     tc.clear()
     spec = mk(folder=g.GENERATED, classname="tmpo_%s_%s" % (which, o), ldlOrder=order(o))
-    kw = dict(g.VARIANT_KW[variant], lds_slots=int(slots), tag="%s_s%s_l%s" % (variant, stage, slots))
+    kw = dict(g.VARIANT_KW[variant], lds_slots=int(slots), tag="%s_s%s_l%s%s" % (variant, stage, slots, "_fine" if rest else ""))
     return cfg, spec, spec.build(**kw)
 
 

@@ -303,7 +303,7 @@ def fused_tape(T, defines):
     return T
 
 
-def assign_slots(T, defines, lds_slots=20000, stage=STAGE):
+def assign_slots(T, defines, lds_slots=20000, stage=STAGE, pack_locals=None):
     """-> dict(addr=int array [n+1] (-1: no storage), nLds, nGlob, nExt, consts=[(addr, value)],
     inputs=[(first global index, numel, entry name)], dummy=LDS slot nobody reads, ...)"""
     from .lowering import Lowering
@@ -377,7 +377,8 @@ def assign_slots(T, defines, lds_slots=20000, stage=STAGE):
     # occupant's last reader has run -- a barrier (W > 1) or the single wavefront's program order lies in between.  For
     # mpc_quadcopter's factor + solves 11 463 values need 5 914 slots; what this frees takes the group's INPUTS into the
     # LDS: before, 575 of its 800 levels waited for a value in HBM.  (TC_LDSM_PACK_LOCALS=0: one slot per value.)
-    pack_locals = os.environ.get("TC_LDSM_PACK_LOCALS", "1") != "0"
+    if pack_locals is None:
+        pack_locals = os.environ.get("TC_LDSM_PACK_LOCALS", "1") != "0"
     local_slot = {}
     sizes = [0]
     if pack_locals:
@@ -1013,7 +1014,10 @@ def copy_records(words, headers, pairs, nLds, W=1):
 
 def class_stream(T, classname, defines, W=1, lds_slots=20000, hoist=True, nested=True, split=True, stage=0):
     """everything the device walk needs for one class"""
-    sl = assign_slots(T, defines, lds_slots, stage=int(stage) or STAGE)
+    # the life times behind the packing of group-local values are those of the DEFAULT schedule (terms staged one step ahead,
+    # nested products): the diagnostic schedules (hoist=False, nested=False: tests/test_ldsm_stream.py) read later than that
+    # and give every local value a slot of its own
+    sl = assign_slots(T, defines, lds_slots, stage=int(stage) or STAGE, pack_locals=None if (hoist and nested) else False)
     addr, nLds = sl["addr"], sl["nLds"]
     st = build_stream(T, addr, nLds, W, stage_base=sl["stage_base"], nStage=sl["nStage"], hoist=hoist,
                       pads=(sl["negzero"], sl["posinf"], sl["neginf"]), one=sl["one"], nested=nested, split=split)

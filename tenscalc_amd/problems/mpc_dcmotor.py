@@ -51,11 +51,15 @@ def mpc_dcmotor(T=30, classname="tmp_mpc_dcmotor", **options):
     uWarm = tc.min2(uWarm, tc.repmat(max_u - .05 * (max_u - min_u), (1, T - 1)))
     outs = dict(J=J, Jx2=Jx2, Ju2=Ju2, t=tc.Tconstant(np.arange(T, dtype=float)) * Ts, u=u, x=x, ref=ref,
                 xWarm=tc.full(xWarm), uWarm=tc.full(uWarm))
-    # Elimination order: greedy minimum degree.  Round 5 measured multiple elimination with tolerance 1
-    # (`ldlOrder=("mmd", 1)`: 440 -> 246 dependent levels per Newton iteration; LDS machine 34.0 -> 21.5 ms per 32768, tile
-    # machine 23.0 -> 20.9, profiles/r05_dcmotor_orders.log) and did not adopt it: on one of three seeds the iterate after
-    # three Newton steps leaves the tape-independent dense IPM by 3e-2 (tests/test_tape_vs_dense_ipm.py) -- the equality
-    # duals' pivots are where that order loses digits (DESIGN.md 7 "numerical finding").
+    # Elimination order of the two KKT factorisations (the reference calls symamd, which is not available: DESIGN.md 7).
+    # Round 5: multiple elimination with degree tolerance 1 -- 177 -> 51 dependent levels in the factor, 440 -> 246 per Newton
+    # iteration over factor + solves, 1.06x the fill; every back-end that walks levels gains (LDS machine 34.0 -> 21.5 ms per
+    # 32768, tile machine 23.0 -> 20.9: profiles/r05_dcmotor_orders.log).  Numerically the two orders are the same: direction
+    # error 4.5e-15 against 3.8e-15 at worst over 60 seeds x 4 stopping points, and either order leaves the tape-independent
+    # dense IPM through a line-search branch (DESIGN.md 4 "knife edge") on 9 / 10 of those 60 seeds -- different ones
+    # (tests/test_tape_vs_dense_ipm.py pins the seeds that agree and asserts the rates).  Tolerance >= 2 does lose digits on the
+    # equality duals (DESIGN.md 7 "numerical finding").
+    options.setdefault("ldlOrder", ("mmd", 1))
     return cmex2optimizeCS(classname=classname, objective=J, optimizationVariables=[u, x],
                            constraints=dynamics + constraints, outputExpressions=list(outs.values()),
                            outputNames=list(outs.keys()),

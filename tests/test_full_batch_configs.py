@@ -74,7 +74,7 @@ def test_l1l2_full_batch_properties():
 def test_dcmotor_full_batch_properties():
     from dense_ipm import dcmotor_qp
     B = 32768
-    spec, ds, st, it, out = _run("dcmotor", "strict", B, seed0=100)      # seeds 100..131 are the golden ones
+    spec, ds, st, it, out = _run("dcmotor", "ldscs", B, seed0=100)       # bench.py's default; seeds 100..131 are the golden ones
     assert (st == 0).all() and it.max() <= 100
     _replicas_equal(st, it, out, B)
     for k in (0, 17, 255):
@@ -88,12 +88,14 @@ def test_dcmotor_full_batch_properties():
     got = np.concatenate([out[nm][:n] for nm in gold["output_names"]], axis=1)
     assert np.array_equal(st[:n], gold["status"]) and np.array_equal(it[:n], gold["iter"])
     assert np.array_equal(got, gold["outputs"])
-    # the per-GPU share of the 8-GPU sweep on the wave-cooperative class: bit for bit what `strict` returns
+    # the per-GPU share of the 8-GPU sweep on the printed-code classes (one thread per instance; 32 lanes per instance):
+    # bit for bit what the LDS machine returns
     B2 = 4096
-    _, _, st2, it2, out2 = _run("dcmotor", "w32x", B2, seed0=100)
-    assert np.array_equal(st2, st[:B2]) and np.array_equal(it2, it[:B2])
-    for k, v in out2.items():
-        assert np.array_equal(v, out[k][:B2]), k
+    for other in ("strict", "w32x"):
+        _, _, st2, it2, out2 = _run("dcmotor", other, B2, seed0=100)
+        assert np.array_equal(st2, st[:B2]) and np.array_equal(it2, it[:B2])
+        for k, v in out2.items():
+            assert np.array_equal(v, out[k][:B2]), (other, k)
 
 
 def test_quadcopter_full_batch_properties():
