@@ -655,6 +655,13 @@ def bench_config(args, R):
     # reduction -- with a stand-in for the per-rank solver and gloo on CPU tensors (tests/test_bench_launcher.py)
     standin = R.standin
     modname, mk, datafn, B0, var0, ncpu, label = CONFIGS[args.config]
+    _t = [time.perf_counter()]
+
+    def phase(name):         # TC_BENCH_TIMING=1: where the wall time of a config sub-line goes (stderr)
+        if os.environ.get("TC_BENCH_TIMING") and rank == 0:
+            now = time.perf_counter()
+            print("[bench %s] %-28s %7.2f s" % (args.config, name, now - _t[0]), file=sys.stderr, flush=True)
+            _t[0] = now
     mod = importlib.import_module(modname)
     SOLVE = mod.SOLVE_ARGS
     if args.total:
@@ -674,6 +681,7 @@ def bench_config(args, R):
             spec.build(**kw)
         R.barrier()
         so = spec.build(**kw)
+    phase("tape + class library")
     names = [n for n, _ in spec.parameters + spec.variables]
     ds = [getattr(mod, datafn)(lo + k) for k in range(B)]                     # distinct instances, seed = global id
     stacked = {n: np.stack([np.asarray(d[n], dtype=float).reshape(-1, order="F") for d in ds]) for n in names}
@@ -684,6 +692,7 @@ def bench_config(args, R):
         for n in names:
             o_.set(n, stacked[n])
     obj = objs[0]
+    phase("data, handles, inputs")
 
     class _NoStream:        # stand-in: nothing is asynchronous
         cuda_stream = None
@@ -749,6 +758,7 @@ def bench_config(args, R):
     elapsed = time.perf_counter() - t0
     ok_all = [int((v[1] == 0).sum().item()) for v in views[:min(P, args.steps)]]      # status of EVERY handle in flight
     elapsed, ok = reduce_timing(elapsed, float(np.mean(ok_all)), world, dev)
+    phase("warm-up + timed steps")
     out = None
     if rank == 0:
         it = IT.cpu().numpy()
@@ -788,8 +798,10 @@ def bench_config(args, R):
         if not args.no_cpu and world == 1 and not standin:
             out["cpu_baseline"] = cpu_baseline_config(spec, args.config, stacked, names, min(B, ncpu), SOLVE, st, it,
                                                       budget_s=getattr(args, "cpu_budget_s", 8.0))
+    phase("cpu baseline + line")
     for o_ in objs:
         o_.close()
+    phase("close")
     return out
 
 
