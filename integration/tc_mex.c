@@ -46,6 +46,8 @@ typedef struct {
   const char *(*iname)(int);
   int64_t (*inumel)(int);
   const char *(*err)(void);
+  int (*profview)(tc_solver_t *, const char *);            /* optional: diagnostics of the reference classes */
+  int (*trace)(tc_solver_t *, int64_t, const char *);
 } obj_t;
 
 #define TCM_MAX 64
@@ -106,6 +108,8 @@ void mexFunction(int nlhs, mxArray *plhs[], int nrhs, const mxArray *prhs[]) {
     *(void **)&o->iname = dlsym(o->lib, "tc_input_name");
     *(void **)&o->inumel = dlsym(o->lib, "tc_input_numel");
     *(void **)&o->err = dlsym(o->lib, "tc_last_error");
+    *(void **)&o->profview = dlsym(o->lib, "tc_profiling_view");
+    *(void **)&o->trace = dlsym(o->lib, "tc_trace");
     if (!o->create || !o->destroy || !o->set || !o->solve || !o->get || !o->nout || !o->ondim || !o->odim ||
         !o->nin || !o->iname || !o->inumel || !o->err) {
       dlclose(o->lib);      /* the slot is free again before the error unwinds */
@@ -179,6 +183,19 @@ void mexFunction(int nlhs, mxArray *plhs[], int nrhs, const mxArray *prhs[]) {
     int rc = o->get(o->h, ptr, o->B);
     mxFree(ptr);
     check(o, rc, "tc_get_outputs");
+  } else if (!strcmp(cmd, "profilingView")) {
+    /* profilingView(obj, filename) of classes generated with profiling=true (writeCprofiling.c:68-75) */
+    char path[4096];
+    need(nrhs == 3 && mxIsChar(prhs[2]) && !mxGetString(prhs[2], path, sizeof path), "profilingView: (handle, filename) expected");
+    need(o->profview != NULL, "profilingView: this class library has no tc_profiling_view");
+    check(o, o->profview(o->h, path), "tc_profiling_view");
+  } else if (!strcmp(cmd, "trace")) {
+    /* the solverVerboseLevel >= 3 iteration table (ipmPD_CSsolver.c:248-345,775-863) of ONE instance, 1-based as in MATLAB */
+    char path[4096];
+    need(nrhs == 4 && mxIsNumeric(prhs[2]) && mxGetNumberOfElements(prhs[2]) == 1 && mxIsChar(prhs[3]) &&
+         !mxGetString(prhs[3], path, sizeof path), "trace: (handle, instance, filename) expected");
+    need(o->trace != NULL, "trace: this class library has no tc_trace");
+    check(o, o->trace(o->h, (int64_t)mxGetScalar(prhs[2]) - 1, path), "tc_trace");
   } else if (!strcmp(cmd, "destroy")) {
     tcm_release(o);        /* the slot's generation stays: this handle value never matches again */
   } else {

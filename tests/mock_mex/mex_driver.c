@@ -201,6 +201,12 @@ static int run_gpu(const char *lib, const char *inpath, const char *outpath) {
   f = fopen(outpath, "wb");
   fwrite(st->data, 4, B, f); fwrite(it->data, 4, B, f); fwrite(J->data, 8, B, f); fwrite(x->data, 8, 8 * B, f);
   fclose(f);
+  /* the diagnostics of the reference classes reach the library too: an ordinary class refuses both with ITS message */
+  in[0] = mxCreateString("profilingView"); in[2] = mxCreateString("/dev/null");
+  EXPECT_ERR(0, out, 3, in, "without profiling");
+  in[0] = mxCreateString("trace"); in[2] = mxCreateDoubleScalar(1.0); in[3] = mxCreateString("/dev/null");
+  EXPECT_ERR(0, out, 4, in, "solverVerboseLevel < 3");
+  EXPECT_ERR(0, out, 3, in, "(handle, instance, filename) expected");
   /* leave h alive: the mexAtExit hook must release it (MATLAB: clear mex) */
   if (!at_exit_fn) { fprintf(stderr, "no mexAtExit hook registered\n"); return 8; }
   at_exit_fn();
