@@ -2091,6 +2091,8 @@ def build_class(spec, fp_contract="fast", arch="gfx950", opt="-O3", block=64, fo
 
     try_flags: compiler flags worth having but not worth failing for (LLVM's experimental scheduling strategies crash
     the compiler on some classes): tried first, dropped if hipcc fails with them; lib<cls>.flags records what was used.
+    A tuple of tuples gives ALTERNATIVES in order of preference (the w8x classes: the experimental iterative-ilp strategy,
+    else LLVM's generic `-misched=ilpmax`, else the default).
 
     key_only: nothing is written or compiled; returns (quick key, source digest) as recorded in <cls><tag>.key /
     <cls><tag>.stamp next to a library -- tests/test_class_digests.py recomputes them from the tracked sources for the
@@ -2110,7 +2112,7 @@ def build_class(spec, fp_contract="fast", arch="gfx950", opt="-O3", block=64, fo
     kq.update(repr((cls, sorted(spec.defines.items()), [(n, tuple(sz)) for n, sz in spec.outputs], fp_contract, arch, opt, block,
                     stats, tag, tuple(extra_flags), roll, min_waves, lanes, recip, fast_div, inline_max, reg_budget, scratch,
                     body, waves, fuse, static_clean, forward, rcache, lds_state, share, branch_free_tails, exact, stg_blocks,
-                    lds_slots, ilp, fw_window, sched_every, tuple(try_flags), refresh_outputs, compiled, lds_stage, os.environ.get("TC_LDS_PAD_SLOTS", ""), os.environ.get("TC_STG_BATCH", ""), os.environ.get("TC_LDSM_FUSE", ""), os.environ.get("TC_INTERP_FUSE", ""), os.environ.get("TC_LDSM_LOOP_MERGE", ""), os.environ.get("TC_LDSC_DEPTH", ""), os.environ.get("TC_LDSM_PACK_LOCALS", ""), os.environ.get("TC_LDSM_ROW_SKEW", ""), os.environ.get("TC_LDSM_LATE_LAST", ""), os.environ.get("TC_LDSM_PAD_PRODUCTS", ""), os.environ.get("TC_LDSM_MERGE_PRODUCTS", ""), os.environ.get("TC_LDSM_COLD_RANK", ""), os.environ.get("TC_LDSC_TWO_PHASE", ""), os.environ.get("TC_LDSC_SPLIT_HBM", ""), os.environ.get("TC_LDSC_SCHEDB", ""), os.environ.get("TC_LDSC_BYTES", ""), os.environ.get("TC_LDSC_WPE", ""), os.environ.get("TC_LDSM_STAGE", ""), os.environ.get("TC_LDSC_CHUNK", ""), os.environ.get("TC_WPE", ""),
+                    lds_slots, ilp, fw_window, sched_every, tuple(tuple(a) if isinstance(a, (tuple, list)) else a for a in try_flags), refresh_outputs, compiled, lds_stage, os.environ.get("TC_LDS_PAD_SLOTS", ""), os.environ.get("TC_STG_BATCH", ""), os.environ.get("TC_LDSM_FUSE", ""), os.environ.get("TC_INTERP_FUSE", ""), os.environ.get("TC_LDSM_LOOP_MERGE", ""), os.environ.get("TC_LDSC_DEPTH", ""), os.environ.get("TC_LDSM_PACK_LOCALS", ""), os.environ.get("TC_LDSM_ROW_SKEW", ""), os.environ.get("TC_LDSM_LATE_LAST", ""), os.environ.get("TC_LDSM_PAD_PRODUCTS", ""), os.environ.get("TC_LDSM_MERGE_PRODUCTS", ""), os.environ.get("TC_LDSM_COLD_RANK", ""), os.environ.get("TC_LDSC_TWO_PHASE", ""), os.environ.get("TC_LDSC_SPLIT_HBM", ""), os.environ.get("TC_LDSC_SCHEDB", ""), os.environ.get("TC_LDSC_BYTES", ""), os.environ.get("TC_LDSC_WPE", ""), os.environ.get("TC_LDSM_STAGE", ""), os.environ.get("TC_LDSC_CHUNK", ""), os.environ.get("TC_WPE", ""),
                     os.environ.get("TC_SWEEP_UNROLL", ""))).encode())
     for f_ in sorted(os.listdir(HERE)):
         if f_.endswith(".py"):
@@ -2144,7 +2146,10 @@ def build_class(spec, fp_contract="fast", arch="gfx950", opt="-O3", block=64, fo
              f"-ffp-contract={fp_contract}", "-I", CSRC, "-I", INCLUDE, "-Wno-unused-value"] + list(extra_flags)
     # (the digest must not depend on where the tree lies: the libraries built here travel to the GPU box, whose
     # checkout is at another path -- with the include directories hashed in, every library was rebuilt there)
-    h = hashlib.sha256((src + " ".join(f for f in flags + list(try_flags) if f not in (CSRC, INCLUDE))).encode())
+    # try_flags: one set of optional flags, or several ALTERNATIVES in order of preference (a tuple of tuples)
+    alternatives = [tuple(a) for a in try_flags] if (try_flags and isinstance(try_flags[0], (tuple, list))) else ([tuple(try_flags)] if try_flags else [])
+    flat_try = [f for a in alternatives for f in a]
+    h = hashlib.sha256((src + " ".join(f for f in flags + flat_try if f not in (CSRC, INCLUDE))).encode())
     for d in _deps_of(src):          # the files this class includes, directly or not: an edit rebuilds only its readers
         h.update(open(d, "rb").read())
     stamp = os.path.join(outdir, f"{cls}{suffix}.stamp")
@@ -2164,13 +2169,12 @@ def build_class(spec, fp_contract="fast", arch="gfx950", opt="-O3", block=64, fo
     write_matlab_class(spec, libname=os.path.basename(so), outdir=outdir)     # @<cls>/<cls>.m
     save_tape(spec.tape, os.path.join(outdir, f"{cls}.tape"))
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
-    used = list(try_flags)
-    cmd = [hipcc] + flags + used + [hip, "-o", so]
-    r = subprocess.run(cmd, capture_output=True, text=True)
-    if r.returncode and try_flags:
-        used = []
-        cmd = [hipcc] + flags + [hip, "-o", so]
+    r = None
+    for used in [list(a) for a in alternatives] + [[]]:          # each alternative in turn, then without any
+        cmd = [hipcc] + flags + used + [hip, "-o", so]
         r = subprocess.run(cmd, capture_output=True, text=True)
+        if not r.returncode:
+            break
     if r.returncode:
         raise RuntimeError(f"hipcc failed for class {cls}:\n{' '.join(cmd)}\n{r.stdout}\n{r.stderr}")
     if compiled:
