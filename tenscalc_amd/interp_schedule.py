@@ -11,11 +11,13 @@ reference prints them, so results do not depend on the packing.
 """
 from __future__ import annotations
 
+import os
+
 import numpy as np
 
 from . import instructions as I
 
-NB = 6          # max operands of an instruction inside an 8-wide record (TC_NB)
+NB = 8          # max operands of an instruction inside an 8-wide record (TC_NB)
 KB = 8          # record width
 KB2, NB2 = 16, 3  # wider records for instructions with few operands
 OP_COPY = 60    # pseudo-opcode: dest <- operand (copies / declareCopy entry points)
@@ -33,6 +35,13 @@ def _pad8(lst, m=8):
 
 
 OP_BARRIER = 2 << 8   # header word 0 of a barrier record (K code 2)
+K_LONG4 = 4           # K code: 4 long instructions of one shape side by side
+L4_CHUNK = 8          # TC_C4: their operands are fetched this many at a time, per instruction
+
+
+def _knob(name, default):
+    """tuning knobs of the record packing (hashed into the class build key by hip_emitter.build_class)"""
+    return float(os.environ.get(name, default))
 
 
 def _records(op, n, aux, items, W=1):
@@ -43,15 +52,36 @@ def _records(op, n, aux, items, W=1):
         if op not in _LONG_OPS:
             raise NotImplementedError(f"table-driven back-end: {n} operands for opcode {I.NAMES.get(op, op)}")
         skip = _DOT_SKIP.get(op, 0)
+        # four of a shape side by side (4 x 8 loads in flight per round instead of one instruction's 32, most of which
+        # are padding when n is 9..16), as long as every wave still gets some
+        l4 = _knob("TC_INTERP_L4_MIN", 1)
+        if l4 > 0 and len(items) >= max(4, l4 * W):
+            k0 = 0
+            while len(items) - k0 >= 2:
+                chunk = items[k0:k0 + 4]
+                chunk = chunk + [chunk[-1]] * (4 - len(chunk))
+                k0 += 4
+                m = n - skip
+                nch = (m + L4_CHUNK - 1) // L4_CHUNK
+                heads = [a[:skip] + [0, 0] for _, a in chunk]
+                w = [op | (K_LONG4 << 8), m, aux, 0, 0, 0, 24 + 32 * nch, 0]
+                w += [d for d, _ in chunk] + [h[0] for h in heads] + [h[1] for h in heads] + [0, 0, 0, 0]
+                bodies = [_pad8(a[skip:], L4_CHUNK) for _, a in chunk]
+                for c in range(nch):
+                    for b in bodies:
+                        w += b[L4_CHUNK * c:L4_CHUNK * (c + 1)]
+                out.append((4 * n + 24 * nch, w))
+            items = items[k0:]
         for d, a in items:
             head = a[:skip] + [0, 0]
             body = _pad8(a[skip:], LONG_CHUNK)      # padded with row 0: loads need no guards
             out.append((n + 24, [op, n - skip, aux, d, head[0], head[1], 8 + len(body), 0] + body))
         return out
     # wide records only while every wave of the block still gets a few of them
-    if n <= NB2 and len(items) >= 12 * W:
+    wm = _knob("TC_INTERP_WIDE_MIN", 3)
+    if n <= NB2 and len(items) >= max(12, 4 * wm * W):
         K = KB2
-    elif n <= NB and len(items) >= 3 * W:
+    elif n <= NB and len(items) >= max(3, wm * W):
         K = KB
     else:
         K = 1
@@ -91,17 +121,81 @@ def _spread(level_records, W, streams):
         streams[k] += [OP_BARRIER, 0, 0, 0, 0, 0, 8, 0]
 
 
-def build_stream(T, row_of, W=1):
+NA_PAIR, NB_PAIR = 6, 3   # operand counts of the producer / the consumer inside a pair record (tc_pair<NA, NB>)
+K_PAIR = 3                # K code of a pair record
+# opcodes tc_pair_vals evaluates (csrc/tc_interp.hip.inc): the shapes that make up nearly all single-reader producers
+PAIR_PRODUCERS = {I.I_sum, I.I_sumprod, I.I_div, I.I_sqr, I.I_2times}
+PAIR_CONSUMERS = {I.I_sum, I.I_sumprod, I.I_div, I.I_plus_minus_dot, I.I_abs, I.I_heaviside}
+
+
+def _pair_records(key, items):
+    """items: (dest row of the consumer, producer operand words, consumer operand words -- the word at position p carries
+    only the sign bit) of one pair shape -> records of 8 pairs (the last one padded by repeating its last pair)"""
+    opB, nB, auxB, opA, nA, auxA, p = key
+    out = []
+    for k0 in range(0, len(items), KB):
+        chunk = items[k0:k0 + KB]
+        chunk = chunk + [chunk[-1]] * (KB - len(chunk))
+        w = [opB | (K_PAIR << 8), nB, auxB, opA | (nA << 8) | (auxA << 16), p, 0, 16 + KB * (nA + nB), 0]
+        w += [d for d, _, _ in chunk]
+        for j in range(nA):
+            w += [a[j] for _, a, _ in chunk]
+        for j in range(nB):
+            w += [b[j] for _, _, b in chunk]
+        out.append((KB * (nA + nB - 1) + 24, w))
+    return out
+
+
+def build_stream(T, row_of, W=1, fusable=None):
     """Returns (words, ranges, level statistics): ranges[g] = [(start, end)] * W, the record range
     each of the W cooperating waves walks for dependency group g+1.
 
-    row_of(j): state row (relative to the scratch base) holding the value of instruction j."""
+    row_of(j): state row (relative to the scratch base) holding the value of instruction j.
+    fusable[j] (optional): instruction j has exactly one reader, in its own group, and no entry point reads it.  Such a
+    producer is evaluated INSIDE its consumer's record (a pair record: 8 producer/consumer pairs of one shape) and never
+    stored: one store and one load of a 512-byte row less per pair.  The arithmetic of both instructions is untouched."""
     words = []
     ranges = []
     stats = []
     opl, ost = T.ops.tolist(), T.opStart.tolist()
     types = T.types
     grp = T.group
+    cache = {}
+
+    def enc(i):
+        """(opcode, aux, operand words, dest row) of instruction i as the evaluator sees it"""
+        if i in cache:
+            return cache[i]
+        op = int(types[i - 1])
+        ops = opl[ost[i - 1]:ost[i]]
+        par = T.pars[T.parStart[i - 1]:T.parStart[i]]
+        aux = 0
+        if op == I.I_sum:
+            a = [row_of(j) * 2 + (0 if p > 0 else 1) for j, p in zip(ops, par)]
+            if len(a) != len(par):
+                raise AssertionError("I_sum sign count")
+        elif op == I.I_sumprod:
+            aux = int(par[0])
+            if aux * int(par[1]) != len(ops):
+                raise AssertionError("I_sumprod operand count")
+            a = [row_of(j) * 2 for j in ops]
+        elif op == I.I_componentwise:
+            eq = I.componentwise_opcode(par)
+            if eq is None:
+                raise NotImplementedError("table-driven back-ends run I_componentwise only for plain calls of "
+                                          + str(sorted(I.COMPONENTWISE_CALLS)) + "; got " + repr(I.componentwise_text(par)))
+            op = eq
+            a = [int(row_of(j)) * 2 for j in ops]
+        elif op > I.I_componentwise or op in (I.I_set, I.I_load):
+            raise NotImplementedError(f"table-driven back-end: opcode {I.NAMES.get(op, op)}")
+        else:
+            a = [row_of(j) * 2 for j in ops]
+        d = row_of(i)
+        if not a:               # I_2, I_zero: give the evaluator something to load
+            a = [d * 2]
+        cache[i] = (op, aux, a, d)
+        return cache[i]
+
     for g, members in enumerate(T.groups, 1):
         lvl = {}
         levels = {}
@@ -112,48 +206,64 @@ def build_stream(T, row_of, W=1):
                     l_ = max(l_, lvl[j] + 1)
             lvl[i] = l_
             levels.setdefault(l_, []).append(i)
+        # ---- producer/consumer pairs -----------------------------------------------------------------------------------
+        host = {}       # consumer -> (producer, operand position)
+        if fusable is not None:
+            cand = {}   # (level of the consumer, pair shape) -> [consumer]
+            for i in members.tolist():
+                ops = opl[ost[i - 1]:ost[i]]
+                if not ops or len(ops) > NB_PAIR or enc(i)[0] not in PAIR_CONSUMERS:
+                    continue
+                for p, j in enumerate(ops):
+                    nj = ost[j] - ost[j - 1] if j >= 1 else 0
+                    if not (fusable[j] and grp[j] == g and j not in host and 1 <= nj <= NA_PAIR):
+                        continue
+                    opB, auxB, aB, _ = enc(i)
+                    opA, auxA, aA, _ = enc(j)
+                    if opA not in PAIR_PRODUCERS:
+                        continue
+                    host[i] = (j, p)
+                    cand.setdefault((lvl[i], (opB, len(aB), auxB, opA, len(aA), auxA, p)), []).append(i)
+                    break
+            for (_, _), lst in cand.items():
+                # a shape needs a few full records per wave; the ragged tail of a shape stays unfused
+                keep = len(lst) if len(lst) >= 3 * W else 0
+                if keep % KB and keep % KB < 3:
+                    keep -= keep % KB
+                for i in lst[keep:]:
+                    del host[i]
+        inside = {j for j, _ in host.values()}
         streams = [[] for _ in range(W)]
+        npair = 0
         for l_ in sorted(levels):
             shapes = {}
+            pshapes = {}
             for i in levels[l_]:
-                op = int(types[i - 1])
-                ops = opl[ost[i - 1]:ost[i]]
-                par = T.pars[T.parStart[i - 1]:T.parStart[i]]
-                aux = 0
-                if op == I.I_sum:
-                    a = [row_of(j) * 2 + (0 if p > 0 else 1) for j, p in zip(ops, par)]
-                    if len(a) != len(par):
-                        raise AssertionError("I_sum sign count")
-                elif op == I.I_sumprod:
-                    aux = int(par[0])
-                    if aux * int(par[1]) != len(ops):
-                        raise AssertionError("I_sumprod operand count")
-                    a = [row_of(j) * 2 for j in ops]
-                elif op == I.I_componentwise:
-                    eq = I.componentwise_opcode(par)
-                    if eq is None:
-                        raise NotImplementedError("table-driven back-ends run I_componentwise only for plain calls of "
-                                                  + str(sorted(I.COMPONENTWISE_CALLS)) + "; got " + repr(I.componentwise_text(par)))
-                    op = eq
-                    a = [int(row_of(j)) * 2 for j in ops]
-                elif op > I.I_componentwise or op in (I.I_set, I.I_load):
-                    raise NotImplementedError(f"table-driven back-end: opcode {I.NAMES.get(op, op)}")
+                if i in inside:
+                    continue
+                op, aux, a, d = enc(i)
+                if i in host:
+                    j, p = host[i]
+                    opA, auxA, aA, _ = enc(j)
+                    b = list(a)
+                    b[p] &= 1                # the producer's value never has a row: keep the sign bit only
+                    pshapes.setdefault((op, len(a), aux, opA, len(aA), auxA, p), []).append((d, aA, b))
+                    npair += 1
                 else:
-                    a = [row_of(j) * 2 for j in ops]
-                d = row_of(i)
-                if not a:               # I_2, I_zero: give the evaluator something to load
-                    a = [d * 2]
-                shapes.setdefault((op, len(a), aux), []).append((d, a))
+                    shapes.setdefault((op, len(a), aux), []).append((d, a))
             recs = []
             for (op, n, aux), items in sorted(shapes.items()):
                 recs += _records(op, n, aux, items, W)
-            _spread(recs, W, streams)
+            for key, items in sorted(pshapes.items()):
+                recs += _pair_records(key, items)
+            if recs:
+                _spread(recs, W, streams)
         rg = []
         for k in range(W):
             rg.append((len(words), len(words) + len(streams[k])))
             words += streams[k]
         ranges.append(rg)
-        stats.append((len(members), len(levels)))
+        stats.append((len(members), len(levels), npair))
     return words, ranges, stats
 
 
@@ -202,6 +312,32 @@ def _record_rows(w, pc):
             raise AssertionError(f"odd product operand count at {pc}")
         skip = _DOT_SKIP.get(op, 0)
         return ([w[pc + 3]] + [x >> 1 for x in w[pc + 8:pc + 8 + n]] + [x >> 1 for x in w[pc + 4:pc + 4 + skip]]), ln
+    if K == K_LONG4:
+        nch = (n + L4_CHUNK - 1) // L4_CHUNK
+        if n < 1 or ln != 24 + 32 * nch or op not in _LONG_OPS:
+            raise AssertionError(f"bad 4-long record at {pc}")
+        if op in _DOT_SKIP and n % 2:
+            raise AssertionError(f"odd product operand count at {pc}")
+        skip = _DOT_SKIP.get(op, 0)
+        rows = w[pc + 8:pc + 12] + [x >> 1 for x in w[pc + 12:pc + 12 + 4 * skip]]
+        for c in range(nch):
+            for q in range(4):
+                v = w[pc + 24 + 32 * c + 8 * q:pc + 24 + 32 * c + 8 * (q + 1)]
+                rows += [x >> 1 for x in v]          # padding words name row 0, which the device does load
+        return rows, ln
+    if K == K_PAIR:
+        nA, p = (w[pc + 3] >> 8) & 255, w[pc + 4]
+        if not (1 <= n <= NB_PAIR and 1 <= nA <= NA_PAIR and 0 <= p < n) or ln != 16 + KB * (nA + n):
+            raise AssertionError(f"bad pair record at {pc}")
+        rows = w[pc + 8:pc + 16] + [x >> 1 for x in w[pc + 16:pc + 16 + KB * nA]]
+        for j in range(n):
+            v = w[pc + 16 + KB * (nA + j):pc + 16 + KB * (nA + j + 1)]
+            if j == p:
+                if any(x >> 1 for x in v):
+                    raise AssertionError(f"pair record at {pc}: the producer's position names a row")
+            else:
+                rows += [x >> 1 for x in v]
+        return rows, ln
     raise AssertionError(f"bad record width {K} at {pc}")
 
 
@@ -259,7 +395,8 @@ def class_stream(T, L, classname, W=1):
         if lf.kind == "priv":
             return int(lf.idx)
         raise AssertionError(lf.kind)
-    words, granges, gstats = build_stream(T, row_of, W)
+    fusable = L.single_local if os.environ.get("TC_INTERP_PAIRS", "1") != "0" else None
+    words, granges, gstats = build_stream(T, row_of, W, fusable)
     copy_rng = {}
     for e in T.copies:
         if any(L.external[d] for d in e["dst"]):

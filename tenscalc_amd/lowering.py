@@ -156,6 +156,7 @@ class Lowering:
         local = computed & ~read_other & ~out_needed
         # inline: local value with exactly one reader (one operand slot)
         inline = local & (nread == 1)
+        self.single_local = inline.copy()    # one reader, in the same group, never read by an entry point (interp pair records)
         if spill_all:
             local = np.zeros(n + 1, dtype=bool)
             inline = np.zeros(n + 1, dtype=bool)

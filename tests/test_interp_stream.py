@@ -101,7 +101,31 @@ def _walk_to_barrier(w, pc, end, m, base):
         op, K, n, aux, ln = w[pc] & 255, w[pc] >> 8, w[pc + 1], w[pc + 2], w[pc + 6]
         if K == 2:
             return pc + ln
-        if K >= 8:
+        if K == isch.K_PAIR:          # 8 producer/consumer pairs: the producer's value goes straight into operand p
+            opA, nA, auxA, p = w[pc + 3] & 255, (w[pc + 3] >> 8) & 255, w[pc + 3] >> 16, w[pc + 4]
+            dest = w[pc + 8:pc + 16]
+            ca = [w[pc + 16 + 8 * j:pc + 24 + 8 * j] for j in range(nA)]
+            cb = [w[pc + 16 + 8 * (nA + j):pc + 24 + 8 * (nA + j)] for j in range(n)]
+            va = [[m[base + (ca[j][k] >> 1)] for j in range(nA)] for k in range(8)]
+            vb = [[m[base + (cb[j][k] >> 1)] if j != p else None for j in range(n)] for k in range(8)]
+            for k in range(8):
+                vb[k][p] = _eval(opA, auxA, va[k], [ca[j][k] & 1 for j in range(nA)])
+            res = [_eval(op, aux, vb[k], [cb[j][k] & 1 for j in range(n)]) for k in range(8)]
+            for k in range(8):
+                m[base + dest[k]] = res[k]
+        elif K == isch.K_LONG4:       # 4 long instructions of one shape, operands in chunks of 8 per instruction
+            sk = DOT_SKIP.get(op, 0)
+            nch = (n + 7) // 8
+            res = []
+            for q in range(4):
+                a = [w[pc + 12 + 4 * h + q] for h in range(sk)]
+                for c in range(nch):
+                    a += w[pc + 24 + 32 * c + 8 * q:pc + 24 + 32 * c + 8 * (q + 1)]
+                a = a[:sk + n]
+                res.append(_eval(op, aux, [m[base + (x >> 1)] for x in a], [x & 1 for x in a]))
+            for q in range(4):
+                m[base + w[pc + 8 + q]] = res[q]
+        elif K >= 8:
             dest = w[pc + 8:pc + 8 + K]
             cols = [w[pc + 8 + K + K * j:pc + 8 + K + K * (j + 1)] for j in range(n)]
             vals = [[m[base + (cols[j][k] >> 1)] for j in range(n)] for k in range(K)]      # all loads first
@@ -155,13 +179,16 @@ def _check(spec, data, tape_oracle, args, W=1):
     needed = sorted({g for e in T.gets for g in e["parents"]})
     for g in needed:
         walk(cs["words"], cs["granges"][g - 1], m, base)
-    bad = 0
+    bad = inside = 0
     for g in needed:
         for i in T.groups[g - 1]:
             a, b = m[base + cs["row_of"](i)], val(i)
-            if not (a == b or (a != a and b != b)):
+            if a != a and b == b and L.single_local[i]:
+                inside += 1                # evaluated inside its consumer's record, never stored
+            elif not (a == b or (a != a and b != b)):
                 bad += 1
     assert bad == 0, f"{bad} instruction values differ from the oracle"
+    assert inside <= sum(cs["gstats"][g - 1][2] for g in needed)
     return cs
 
 
@@ -187,7 +214,10 @@ def test_stream_dcmotor(native_built, tape_oracle, tmp_path, W):
     """W=4: the records of every level spread over 4 cooperating waves, barrier records in between"""
     from tenscalc_amd.problems.mpc_dcmotor import SOLVE_ARGS, dcmotor_data, mpc_dcmotor
     spec = mpc_dcmotor(folder=str(tmp_path))
-    _check(spec, dcmotor_data(7), tape_oracle, SOLVE_ARGS, W)
+    cs = _check(spec, dcmotor_data(7), tape_oracle, SOLVE_ARGS, W)
+    kinds = {cs["words"][pc] >> 8 for pc in _headers(cs)}
+    assert {isch.K_PAIR, isch.K_LONG4} <= kinds      # producer/consumer pairs and 4-at-a-time long records occur
+    assert sum(s_[2] for s_ in cs["gstats"]) > 1000  # ... pairs: more than a thousand producers never stored
 
 
 def test_stream_small_quadcopter(native_built, tape_oracle, tmp_path):
@@ -204,5 +234,35 @@ def test_validator_rejects_out_of_tile_rows(sls_spec):
     w = list(cs["words"])
     pc = cs["granges"][0][0][0]
     w[pc + 8] = cs["hi"] * 2 + 100          # first operand/dest word of the first record
+    with pytest.raises(AssertionError):
+        isch.validate_stream(w, cs["granges"], cs["lo"], cs["hi"])
+
+
+def test_validator_checks_pair_and_four_long_records(sls_spec):
+    """every row of a pair record (both instructions' operands, except the producer's position, which must not name a row)
+    and of a 4-long record (heads, every round's vectors) is checked on the host before the device walks the stream"""
+    T = sls_spec.tape
+    L = Lowering(T, None, roll=False, lanes=1, spill_all=True)
+    cs = isch.class_stream(T, L, sls_spec.classname)
+    first = {}
+    for pc in _headers(cs):
+        first.setdefault(cs["words"][pc] >> 8, pc)
+    assert isch.K_PAIR in first and isch.K_LONG4 in first
+    pc = first[isch.K_PAIR]
+    nA, n, p = (cs["words"][pc + 3] >> 8) & 255, cs["words"][pc + 1], cs["words"][pc + 4]
+    for off in (16 + 8 * nA - 1,                          # last operand word of the producers
+                16 + 8 * (nA + p) + 3):                   # the producer's own position inside the consumer
+        w = list(cs["words"])
+        w[pc + off] = cs["hi"] * 2 + 64
+        with pytest.raises(AssertionError):
+            isch.validate_stream(w, cs["granges"], cs["lo"], cs["hi"])
+    pc = first[isch.K_LONG4]
+    for off in (9, 24 + 32 * ((cs["words"][pc + 1] + 7) // 8) - 1):    # a destination, the very last (padding) word
+        w = list(cs["words"])
+        w[pc + off] = cs["hi"] * 2 + 64
+        with pytest.raises(AssertionError):
+            isch.validate_stream(w, cs["granges"], cs["lo"], cs["hi"])
+    w = list(cs["words"])
+    w[pc + 6] += 8                                         # wrong length
     with pytest.raises(AssertionError):
         isch.validate_stream(w, cs["granges"], cs["lo"], cs["hi"])
