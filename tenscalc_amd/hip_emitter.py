@@ -1753,7 +1753,9 @@ def emit_class_ldsm(spec, waves=4, stats=False, lds_slots=20000, fuse_chain=True
     w.append("#include <hip/hip_runtime.h>\n#include <math.h>\n#include <float.h>\n#include <stdint.h>\n\n")
     w.append(f'#define TC_CLASSNAME "{cls}"\n#define TC_BLOCK {64 * W}\n#define TC_P 1\n#define TC_G TC_BLOCK\n'
              f"#define TC_NDIST 0\n#define TC_LDSM 1\n#define TC_W {W}\n#define TC_NLDS {cs['nLds']}\n#define TC_NGLOB {max(1, cs['nGlob'])}\n"
-             f"#define TC_LAUNCH_BOUNDS __launch_bounds__(TC_BLOCK)\n")
+             "#define TC_LAUNCH_BOUNDS __launch_bounds__(TC_BLOCK)"
+             + (" __attribute__((amdgpu_waves_per_eu({0}, {1})))".format(*(os.environ["TC_WPE"].split("-") * 2)[:2])
+                if os.environ.get("TC_WPE") else "") + "\n")
     if stats:
         # stats="levels" (compiled walk only): wavefront 0 of block 0 writes (record, clock) into the dbg buffer whenever
         # it enters a level; the cursor lives in the last padding slot of the staging area (scripts/level_trace.py)
