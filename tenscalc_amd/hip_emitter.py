@@ -1726,9 +1726,11 @@ def _ldsc_functions(cs, W, chunk=96, depth=12, trace=False):
     return "".join(w)
 
 
-def emit_class_ldsm(spec, waves=4, stats=False, lds_slots=20000, fuse_chain=True, compiled=False, lds_stage=0):
+def emit_class_ldsm(spec, waves=4, stats=False, lds_slots=20000, fuse_chain=True, compiled=False, lds_stage=0, min_waves=0):
     """body="ldsm": ONE instance per workgroup of `waves` wavefronts, hot state in LDS, the tape as data whose
-    records give every lane a different scalar instruction (csrc/tc_ldsm.hip.inc, ldsm_schedule.py)."""
+    records give every lane a different scalar instruction (csrc/tc_ldsm.hip.inc, ldsm_schedule.py).
+    min_waves=k: the kernel is compiled for k wavefronts per SIMD (512 / k registers), so that as many workgroups as the LDS
+    budget allows are really resident -- 4 instances x 2 wavefronts per CU need 2 per SIMD."""
     from . import ldsm_schedule as lsch
     if _solver_of(spec) == "ipmPDeq_CSsolver":
         raise NotImplementedError("body='ldsm' packs the state by life times derived from the call structure of "
@@ -1750,12 +1752,12 @@ def emit_class_ldsm(spec, waves=4, stats=False, lds_slots=20000, fuse_chain=True
              f"// tape: {T.n} instructions, {T.nGroups} dependency groups; state: {cs['nLds']} LDS slots "
              f"({cs['nHot']} hot shared, {cs['nLocal']} group-local scratch), {cs['nGlob']} doubles in HBM per instance "
              f"({cs['nExt']} inputs, {cs['nCold']} cold); {len(cs['headers']) // 8} records, {len(cs['words'])} body words\n")
+    wpe_ = os.environ.get("TC_WPE") or (str(int(min_waves)) if min_waves else "")     # TC_WPE: tuning aid (hashed into the key)
     w.append("#include <hip/hip_runtime.h>\n#include <math.h>\n#include <float.h>\n#include <stdint.h>\n\n")
     w.append(f'#define TC_CLASSNAME "{cls}"\n#define TC_BLOCK {64 * W}\n#define TC_P 1\n#define TC_G TC_BLOCK\n'
              f"#define TC_NDIST 0\n#define TC_LDSM 1\n#define TC_W {W}\n#define TC_NLDS {cs['nLds']}\n#define TC_NGLOB {max(1, cs['nGlob'])}\n"
              "#define TC_LAUNCH_BOUNDS __launch_bounds__(TC_BLOCK)"
-             + (" __attribute__((amdgpu_waves_per_eu({0}, {1})))".format(*(os.environ["TC_WPE"].split("-") * 2)[:2])
-                if os.environ.get("TC_WPE") else "") + "\n")
+             + (" __attribute__((amdgpu_waves_per_eu({0}, {1})))".format(*(wpe_.split("-") * 2)[:2]) if wpe_ else "") + "\n")
     if stats:
         # stats="levels" (compiled walk only): wavefront 0 of block 0 writes (record, clock) into the dbg buffer whenever
         # it enters a level; the cursor lives in the last padding slot of the staging area (scripts/level_trace.py)
@@ -2134,7 +2136,7 @@ def build_class(spec, fp_contract="fast", arch="gfx950", opt="-O3", block=64, fo
         if fp_contract != "off":
             raise ValueError("body='ldsm' is a bit-exact back-end: fp_contract='off'")
         src, L = emit_class_ldsm(spec, waves=waves, stats=stats, lds_slots=lds_slots,      # TC_LDSM_FUSE=0: no fused walk
-                                 compiled=bool(compiled), lds_stage=lds_stage)
+                                 compiled=bool(compiled), lds_stage=lds_stage, min_waves=min_waves)
     else:
       src, L = emit_class(spec, fp_contract=fp_contract, block=block, stats=stats, roll=roll,
                         min_waves=min_waves, lanes=lanes, recip=recip, fast_div=fast_div, inline_max=inline_max,
