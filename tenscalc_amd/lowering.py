@@ -68,11 +68,13 @@ class Lowering:
     # slot sharing: exempt volatile values from surviving a whole inner loop (see life()).  Sound (CPU replay of
     # real call traces, bit-exact on the GPU) and worth 26 slots on sls -- a seventh wavefront per CU -- but the
     # tighter reuse costs as much as the wavefront gains (0.72 vs 0.66 ms at equal occupancy, 0.66 at 7 per CU):
-    # off by default, TC_FINE_LIVES=1 to enable
-    FINE_LIVES = os.environ.get("TC_FINE_LIVES", "0") == "1"
+    # off by default, TC_FINE_LIVES=1 to enable (read when a Lowering is made; hashed into the class build key)
+    FINE_LIVES = None
 
     def __init__(self, tape, code=None, roll=True, lanes=1, _replicate=(), mine=None, spill_all=False,
                  share=None):
+        if self.FINE_LIVES is None:
+            self.FINE_LIVES = os.environ.get("TC_FINE_LIVES", "0") == "1"
         T = self.T = tape
         # share: the solver #define block -> values of transient groups whose life times inside one pass of
         # the Newton loop do not overlap share storage (_assign_shared_slots); None: one slot per value
