@@ -1214,7 +1214,7 @@ def emit_class(spec, fp_contract="fast", block=64, stats=False, roll=True, min_w
     if interp:
         from . import interp_schedule as isch
         cs = isch.class_stream(T, L, cls, int(waves))
-        stream, granges, gstats = cs["words"], cs["granges"], cs["gstats"]
+        stream, granges, gstats = cs["dev_words"], cs["granges"], cs["gstats"]      # rows as byte offsets (device_words)
         copy_rng, out_rng, consts = cs["copy_rng"], cs["out_rng"], cs["consts"]
         arr = isch.as_array(stream + [0] * 8)          # the header prefetch looks one record past the end
         w.append(f"// the tape as data: {arr.size} words, {len(consts)} constants\n"

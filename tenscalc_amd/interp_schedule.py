@@ -371,6 +371,72 @@ def validate_stream(words, ranges, lo, hi):
             raise AssertionError("waves of one range do not meet the same number of barriers")
 
 
+ROW_BYTES = 512       # one row of a tile: 64 instances x 8 bytes
+
+
+def device_words(words, ranges, lo):
+    """The stream as the device walks it.  The builder, the validator and the CPU model of the walk speak in ROWS (dest
+    words are rows, operand words row*2+neg); the device addresses the tile through a buffer descriptor whose base is the
+    tile's first row, so every dest / operand word of every record becomes that row's BYTE OFFSET (row - lo) * 512, with
+    the sign bit of an I_sum operand still in bit 0: one scalar AND and one buffer_load per operand instead of three scalar
+    shifts, a 64-bit vector add and a global_load.  Words outside the record ranges (the output gather table) stay rows."""
+    w = list(words)
+    done = set()
+
+    def dst(k):
+        w[k] = (words[k] - lo) * ROW_BYTES
+
+    def opd(k):
+        w[k] = ((words[k] >> 1) - lo) * ROW_BYTES | (words[k] & 1)
+
+    for rg in ranges:
+        for start, end in rg:
+            pc = start
+            while pc < end:
+                op, K, n, ln = words[pc] & 255, words[pc] >> 8, words[pc + 1], words[pc + 6]
+                if pc in done:
+                    raise AssertionError("record in two ranges")
+                done.add(pc)
+                if K in (KB, KB2):
+                    for k in range(pc + 8, pc + 8 + K):
+                        dst(k)
+                    for k in range(pc + 8 + K, pc + 8 + K + K * n):
+                        opd(k)
+                elif K == 1:
+                    dst(pc + 3)
+                    for k in range(pc + 8, pc + 8 + n):
+                        opd(k)
+                elif K == 0:
+                    dst(pc + 3)
+                    for k in range(pc + 4, pc + 4 + _DOT_SKIP.get(op, 0)):
+                        opd(k)
+                    for k in range(pc + 8, pc + ln):          # the padding names row 0: the device does load it
+                        opd(k)
+                elif K == K_LONG4:
+                    for k in range(pc + 8, pc + 12):
+                        dst(k)
+                    for k in range(pc + 12, pc + 20):         # heads (row 0 where the opcode has none)
+                        opd(k)
+                    for k in range(pc + 24, pc + ln):
+                        opd(k)
+                elif K == K_PAIR:
+                    nA, p = (words[pc + 3] >> 8) & 255, words[pc + 4]
+                    for k in range(pc + 8, pc + 16):
+                        dst(k)
+                    for k in range(pc + 16, pc + 16 + KB * nA):
+                        opd(k)
+                    for j in range(n):
+                        if j != p:                             # position p carries sign bits only
+                            for k in range(pc + 16 + KB * (nA + j), pc + 16 + KB * (nA + j + 1)):
+                                opd(k)
+                elif words[pc] != OP_BARRIER:
+                    raise AssertionError(f"bad record width {K} at {pc}")
+                pc += ln
+    if any(x < 0 or x >= 2 ** 31 for k in done for x in w[k + 8:k + words[k + 6]]):
+        raise OverflowError("byte offset of a row outside [0, 2 GB)")
+    return w
+
+
 def constant_rows(T, L):
     """constants read by instructions get rows of their own above the computed values"""
     consts, const_row = [], {}
@@ -411,6 +477,7 @@ def class_stream(T, L, classname, W=1):
     if out_rows and (min(out_rows) < lo or max(out_rows) >= hi):
         raise AssertionError("output row outside the tile")
     out_rng = gather_table(words, out_rows)
+    dev_words = device_words(words, granges + list(copy_rng.values()), lo)
     # range table the device indexes by (range id, wave): groups first, then the copies
     rid = {}
     table = []
@@ -420,7 +487,7 @@ def class_stream(T, L, classname, W=1):
     for name, rg in copy_rng.items():
         rid[name] = len(table) // (2 * W)
         table += [x for se in rg for x in se]
-    return dict(words=words, granges=granges, gstats=gstats, copy_rng=copy_rng, out_rng=out_rng,
+    return dict(words=words, dev_words=dev_words, granges=granges, gstats=gstats, copy_rng=copy_rng, out_rng=out_rng,
                 consts=consts, const_row=const_row, row_of=row_of, lo=lo, hi=hi, W=W, rid=rid, table=table)
 
 

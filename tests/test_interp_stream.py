@@ -266,3 +266,31 @@ def test_validator_checks_pair_and_four_long_records(sls_spec):
     w[pc + 6] += 8                                         # wrong length
     with pytest.raises(AssertionError):
         isch.validate_stream(w, cs["granges"], cs["lo"], cs["hi"])
+
+
+def test_device_words_are_the_same_stream_in_byte_offsets(sls_spec):
+    """what the device walks (interp_schedule.device_words): every dest / operand word of every record is its row's byte
+    offset from the first row of the tile, sign bit kept; headers, the producer's position of a pair record and the output
+    gather table are untouched -- decoded back it is the builder's stream word for word"""
+    T = sls_spec.tape
+    L = Lowering(T, None, roll=False, lanes=1, spill_all=True)
+    for W in (1, 4):
+        cs = isch.class_stream(T, L, sls_spec.classname, W)
+        w, dv, lo = cs["words"], cs["dev_words"], cs["lo"]
+        assert len(w) == len(dv)
+        changed = [k for k in range(len(w)) if w[k] != dv[k]]
+        assert changed
+        rows_hi = (cs["hi"] - lo) * isch.ROW_BYTES
+        nd = 0
+        for k in changed:
+            assert 0 <= dv[k] < rows_hi + 1 and (dv[k] & ~1) % isch.ROW_BYTES == 0
+            as_dest, as_operand = dv[k] // isch.ROW_BYTES + lo, ((dv[k] >> 9) + lo) * 2 + (dv[k] & 1)
+            assert w[k] in (as_dest, as_operand)
+            nd += w[k] == as_dest
+        assert nd > 0
+        heads = set(_headers(cs))
+        for pc in heads:                     # opcode / count / aux / length words never change
+            for q in (0, 1, 2, 6, 7):
+                assert dv[pc + q] == w[pc + q]
+        s, n = cs["out_rng"]
+        assert dv[s:s + n] == w[s:s + n]      # tc_gather reads rows
