@@ -1226,7 +1226,9 @@ def emit_class(spec, fp_contract="fast", block=64, stats=False, roll=True, min_w
                  "static __device__ const int tc_rng[] __attribute__((aligned(64))) = {"
                  + ", ".join(str(int(x)) for x in cs["table"]) + "};\n"
                  f"#define TC_NCONST {len(consts)}\n#define TC_NPRIV {L.nPriv}\n#define TC_W {int(waves)}\n"
-                 '#include "tc_interp.hip.inc"\n\n')
+                 "// the record shapes / opcodes of THIS stream (interp_schedule.shape_masks): nothing else is instantiated\n"
+                 + "".join(f"#define TC_OPS_{k} 0x{v:x}ULL\n" for k, v in sorted(cs["shapes"].items()))
+                 + '#define TC_OPS_GIVEN 1\n#include "tc_interp.hip.inc"\n\n')
         for g, members in enumerate(T.groups, 1):
             w.append(f"// group {g}: {len(members)} instructions in {gstats[g - 1][1]} levels, "
                      f"{int(T.flops[g].sum())} flops\n"

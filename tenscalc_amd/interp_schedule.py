@@ -437,6 +437,33 @@ def device_words(words, ranges, lo):
     return w
 
 
+def shape_masks(words, ranges):
+    """Which record shapes and opcodes a class's stream contains: {"16_2": opcode bit mask, "8_3": ..., "1_7": ..., "long": ...,
+    "long4": ..., "pairs": bit (nA-1)*3+(nB-1)}.  hip_emitter prints them as TC_OPS_* macros and csrc/tc_interp.hip.inc
+    instantiates only those shapes, each with only those opcode arms (the dispatcher of a class is a third of the generic
+    one: less to compile, and the arms a wavefront does run sit closer together in the instruction cache)."""
+    m = {}
+    for rg in ranges:
+        for start, end in rg:
+            pc = start
+            while pc < end:
+                op, K, n = words[pc] & 255, words[pc] >> 8, words[pc + 1]
+                if op >= 64:
+                    raise AssertionError("opcode outside the 64-bit masks")
+                if K in (KB, KB2, 1):
+                    key = "%d_%d" % (K, n)
+                    m[key] = m.get(key, 0) | (1 << op)
+                elif K == 0:
+                    m["long"] = m.get("long", 0) | (1 << op)
+                elif K == K_LONG4:
+                    m["long4"] = m.get("long4", 0) | (1 << op)
+                elif K == K_PAIR:
+                    nA = (words[pc + 3] >> 8) & 255
+                    m["pairs"] = m.get("pairs", 0) | (1 << ((nA - 1) * NB_PAIR + (n - 1)))
+                pc += words[pc + 6]
+    return m
+
+
 def constant_rows(T, L):
     """constants read by instructions get rows of their own above the computed values"""
     consts, const_row = [], {}
@@ -478,6 +505,7 @@ def class_stream(T, L, classname, W=1):
         raise AssertionError("output row outside the tile")
     out_rng = gather_table(words, out_rows)
     dev_words = device_words(words, granges + list(copy_rng.values()), lo)
+    shapes = shape_masks(words, granges + list(copy_rng.values()))
     # range table the device indexes by (range id, wave): groups first, then the copies
     rid = {}
     table = []
@@ -487,7 +515,7 @@ def class_stream(T, L, classname, W=1):
     for name, rg in copy_rng.items():
         rid[name] = len(table) // (2 * W)
         table += [x for se in rg for x in se]
-    return dict(words=words, dev_words=dev_words, granges=granges, gstats=gstats, copy_rng=copy_rng, out_rng=out_rng,
+    return dict(words=words, dev_words=dev_words, shapes=shapes, granges=granges, gstats=gstats, copy_rng=copy_rng, out_rng=out_rng,
                 consts=consts, const_row=const_row, row_of=row_of, lo=lo, hi=hi, W=W, rid=rid, table=table)
 
 
