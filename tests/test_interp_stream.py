@@ -294,3 +294,38 @@ def test_device_words_are_the_same_stream_in_byte_offsets(sls_spec):
                 assert dv[pc + q] == w[pc + q]
         s, n = cs["out_rng"]
         assert dv[s:s + n] == w[s:s + n]      # tc_gather reads rows
+
+
+def test_shape_masks_cover_every_record_the_device_can_meet(native_built, tmp_path):
+    """the per-class dispatcher (csrc/tc_interp.hip.inc under TC_OPS_*) instantiates only the shapes / opcodes of
+    interp_schedule.shape_masks: every record of every range the device walks -- groups AND copy entry points -- must be
+    in them, and the generated source must carry exactly those macros"""
+    from tenscalc_amd import hip_emitter as he
+    from tenscalc_amd.problems.mpc_dcmotor import mpc_dcmotor
+    from tenscalc_amd import ldsm_schedule as lsch
+    spec = mpc_dcmotor(folder=str(tmp_path))
+    T = lsch.fused_tape(spec.tape, spec.defines)            # the groups the emitter walks (hip_emitter.emit_class)
+    L = Lowering(T, None, roll=False, lanes=1, spill_all=True)
+    cs = isch.class_stream(T, L, spec.classname, 4)
+    m, w = cs["shapes"], cs["words"]
+    seen = set()
+    for rg in cs["granges"] + list(cs["copy_rng"].values()):
+        for s, e in rg:
+            pc = s
+            while pc < e:
+                op, K, n = w[pc] & 255, w[pc] >> 8, w[pc + 1]
+                if K in (16, 8, 1):
+                    assert (m["%d_%d" % (K, n)] >> op) & 1
+                    seen.add("%d_%d" % (K, n))
+                elif K == 0:
+                    assert (m["long"] >> op) & 1
+                elif K == isch.K_LONG4:
+                    assert (m["long4"] >> op) & 1
+                elif K == isch.K_PAIR:
+                    assert (m["pairs"] >> ((((w[pc + 3] >> 8) & 255) - 1) * 3 + n - 1)) & 1
+                pc += w[pc + 6]
+    assert seen == {k for k in m if k[0].isdigit()}              # ... and no shape is listed that does not occur
+    src = he.emit_class(spec, fp_contract="off", body="interp", waves=4)[0]
+    for k, v in m.items():
+        assert "#define TC_OPS_%s 0x%xULL\n" % (k, v) in src
+    assert src.count("#define TC_OPS_") == len(m) + 1            # + TC_OPS_GIVEN
