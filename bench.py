@@ -433,6 +433,7 @@ def bench_sls(args, R):
                                    + ("after every step, overlapped with the next solve" if every else "once after the K steps")},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBPS, "traffic": measured_traffic(args.variant, B),
+                         "traffic_from": traffic_from(args.variant, B),
                          "kernel": "tc_solve_kernel", "kernel_ms_avg": kavg * 1e3,
                          "kernel_ms_from": ("HIP event pair per launch on the launch stream" if per_step else
                                             "one HIP event pair around the K launches on the launch stream: span / K"),
@@ -509,6 +510,60 @@ def lane_redundancy(variant, B, flops_per_solve):
         return e["sq_insts_valu"] * 64.0 / (flops_per_solve * B) if e and e.get("sq_insts_valu") else None
     except (OSError, ValueError, KeyError, ZeroDivisionError):
         return None
+
+
+def iteration_spread(it, variant, B, kernel_s, calib=None):
+    """How much of a batch is its tail.  `iter_hist`: Newton iterations per instance in 8 bins; `straggler_floor_ms`: the
+    slowest instance ALONE -- iter_max x the time one Newton iteration of one instance takes on this back-end; the batch
+    cannot end before its slowest instance does, wherever the dispatcher started it.  For the back-ends that give an
+    instance a workgroup of its own (`lds*`) the per-iteration time is MEASURED in this run: `calib` = (seconds, iterations
+    of the slowest instance) of one more solve of the first <= 256 instances, each alone on its CU, whose time is that
+    instance's.  `throughput_floor_ms` = all iterations of the batch at that rate over the CUs (x residents per CU where the
+    class admits several).  For the tile back-ends an instance's iterations are not separable from its tile's: the floor
+    is iter_max x kernel / mean(tile maxima), and `lockstep_waste` the share of a tile's walk spent on finished lanes."""
+    import numpy as np
+    it = np.asarray(it, dtype=np.int64)
+    lo, hi = int(it.min()), int(it.max())
+    edges = np.unique(np.round(np.geomspace(max(lo, 1), max(hi, 2) + 1, 9)).astype(np.int64))
+    hist, edges = np.histogram(it, bins=edges)
+    out = {"iter_mean": float(it.mean()), "iter_total": int(it.sum()),
+           "iter_hist": {"edges": [int(e) for e in edges], "counts": [int(c) for c in hist]}}
+    if variant.startswith("lds"):
+        if calib:
+            CUS = 256
+            t_iter = calib[0] / max(int(calib[1]), 1)                  # seconds per Newton iteration of one instance
+            out["ms_per_iteration_one_instance"] = t_iter * 1e3
+            out["ms_per_iteration_from"] = "one solve of the first %d instances (one per CU): %.2f ms / %d iterations of its slowest" % (
+                calib[2], calib[0] * 1e3, calib[1])
+            out["straggler_floor_ms"] = hi * t_iter * 1e3
+            out["throughput_floor_ms"] = float(it.sum()) * t_iter * 1e3 / min(CUS, B)      # (one resident per CU)
+            out["batch_over_floor"] = kernel_s * 1e3 / max(out["straggler_floor_ms"], out["throughput_floor_ms"])
+            out["tail_note"] = ("one instance per workgroup: batch >= max(straggler_floor_ms, throughput_floor_ms); the straggler "
+                                "starts when the workgroup dispatcher reaches it, which no launch order can know in advance")
+    else:
+        tiles = it[:len(it) // 64 * 64].reshape(-1, 64).max(axis=1) if len(it) >= 64 else it[None].max(axis=1)
+        out["tile_iter_max_mean"] = float(tiles.mean())
+        out["straggler_floor_ms"] = kernel_s * 1e3 * hi / float(tiles.mean())
+        out["lockstep_waste"] = 1.0 - float(it.mean()) / float(tiles.mean())       # share of a tile's walk spent on finished lanes
+    return out
+
+
+def traffic_from(variant, B):
+    """where `roofline.traffic` / `lane_redundancy` of this line come from: they are REPLAYED from a committed counter pass
+    (profiles/traffic.json, builder-run rocprofv3 --pmc passes of this same command on another box, possibly in an earlier
+    round), not measured during this run -- the JSON says so itself"""
+    key = "%s_B%d" % (variant, B)
+    try:
+        with open(os.path.join(ROOT, "profiles", "traffic.json")) as f:
+            e = json.load(f).get(key)
+    except (OSError, ValueError):
+        e = None
+    if not e:
+        return None
+    return {"file": "profiles/traffic.json", "entry": key, "round": e.get("round"),
+            "how": "replayed: separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE (and SQ_INSTS_VALU) passes of this command, "
+                   "run by the builder on another MI355X box in that round; NOT a measurement of this run",
+            "kernel_ms_of_that_run": e.get("kernel_avg_ns", 0) * 1e-6 or None}
 
 
 def measured_traffic(variant, B):
@@ -760,6 +815,19 @@ def bench_config(args, R):
     elapsed, ok = reduce_timing(elapsed, float(np.mean(ok_all)), world, dev)
     phase("warm-up + timed steps")
     out = None
+    calib = None
+    if rank == 0 and not standin and variant.startswith("lds") and P == 1:
+        # the time of ONE Newton iteration of ONE instance on this back-end, measured: the first <= 256 instances, one per
+        # CU, in a batch of their own -- its time is its slowest instance's (see iteration_spread)
+        Bc = min(B, 256)
+        oc = HipSolver(so, B=Bc, device=local)
+        for n in names:
+            oc.set(n, stacked[n][:Bc])
+        oc.solve(**SOLVE)
+        _, itc, tmc = oc.solve(**SOLVE)
+        calib = (float(tmc), int(np.asarray(itc).max()), Bc)
+        oc.close()
+        phase("per-iteration calibration")
     if rank == 0:
         it = IT.cpu().numpy()
         st = ST.cpu().numpy()
@@ -783,12 +851,18 @@ def bench_config(args, R):
                           "variant": variant, **parity_fields(g.PARITY_CLASS.get(variant, "solver-tolerance"), spec.tape, spec.defines),
                           "pipeline": P, "distinct_instances": B,
                           "solved_fraction": ok / total, "iter_median": float(np.median(it)),
-                          "iter_max": int(it.max()), "devices": R.devices,
+                          "iter_max": int(it.max()), **iteration_spread(it, variant, B, kavg, calib),
+                          "devices": R.devices,
                           "sharding": "independent instances per rank; one RCCL all_gather of the results after the K steps"},
                "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                             "frac": achieved / HBM_PEAK_GBPS, "traffic": measured_traffic(args.config + "_" + variant, B),
+                            "traffic_from": traffic_from(args.config + "_" + variant, B),
                             "kernel": "tc_solve_kernel", "kernel_ms_avg": kavg * 1e3, "kernel_ms_from": kernel_note,
-                            "algorithmic_bytes_per_launch": algo * B, "algorithmic_bytes_per_solve": algo}}
+                            "algorithmic_bytes_per_launch": algo * B, "algorithmic_bytes_per_solve": algo,
+                            # SURVEY.md 8d's formula, counted from the problem statement: mpc_dcmotor has 42 + 89 input and
+                            # 241 output doubles (mpc_dcmotor.m:118-126: J, Jx2, Ju2, t[30], u[29], x[60], ref[30], xWarm[60],
+                            # uWarm[29]) = 2 984 B; the survey's 3 224 counts 271 outputs, 30 more than the file declares
+                            "algorithmic_doubles": {"inputs": nin, "outputs": nout, "status_iter": 1}}}
         if standin:
             out["data"] = "STAND-IN: no solver ran (TC_BENCH_STANDIN rehearsal of the multi-rank control flow)"
             out["standin"] = True

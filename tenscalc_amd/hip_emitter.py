@@ -2049,18 +2049,23 @@ def class_header(spec):
     return s
 
 
-def _largest_function(so, prefix=""):
+def _largest_function(so, prefix="", arch="gfx950"):
     """(name, bytes) of the largest device function of a class library whose name contains `prefix` (code-object symbol
-    table; ("", 0) when there is none)"""
+    table; ("", 0) when there is none).  Raises RuntimeError when the LLVM tools that read the code object fail."""
     import re
     import tempfile
     llvm = os.environ.get("TC_LLVM_BIN", "/opt/rocm/lib/llvm/bin")
     with tempfile.TemporaryDirectory() as d:
         fb, co = os.path.join(d, "k.fatbin"), os.path.join(d, "k.co")
-        subprocess.run([os.path.join(llvm, "llvm-objcopy"), "-O", "binary", "--only-section=.hip_fatbin", so, fb], check=True)
-        subprocess.run([os.path.join(llvm, "clang-offload-bundler"), "--unbundle", "--type=o", "--input=" + fb,
-                        "--targets=hipv4-amdgcn-amd-amdhsa--gfx950", "--output=" + co], check=True, capture_output=True)
-        txt = subprocess.run([os.path.join(llvm, "llvm-readelf"), "-s", "-W", co], capture_output=True, text=True, check=True).stdout
+        try:
+            subprocess.run([os.path.join(llvm, "llvm-objcopy"), "-O", "binary", "--only-section=.hip_fatbin", so, fb], check=True,
+                           capture_output=True)
+            subprocess.run([os.path.join(llvm, "clang-offload-bundler"), "--unbundle", "--type=o", "--input=" + fb,
+                            "--targets=hipv4-amdgcn-amd-amdhsa--" + arch, "--output=" + co], check=True, capture_output=True)
+            txt = subprocess.run([os.path.join(llvm, "llvm-readelf"), "-s", "-W", co], capture_output=True, text=True,
+                                 check=True).stdout
+        except (OSError, subprocess.CalledProcessError) as e:
+            raise RuntimeError("cannot read the code object of %s (%s): %s" % (so, arch, getattr(e, "stderr", None) or e))
     best = ("", 0)
     for ln in txt.splitlines():
         m = re.match(r"\s*\d+:\s+[0-9a-f]+\s+(\d+)\s+FUNC\s+\S+\s+\S+\s+\S+\s+(\S+)", ln)
@@ -2105,6 +2110,15 @@ def build_class(spec, fp_contract="fast", arch="gfx950", opt="-O3", block=64, fo
     shipped (git-ignored) libraries.  key_only="quick": the quick key alone, without emitting the source."""
     from .tapeio import save_tape, tape_records, _rec
     cls = spec.classname
+    if int(spec.defines.get("verboseLevel", 0)) >= 3:
+        # the iteration table is recorded by ONE thread per traced instance (csrc/ipm_newton.hip.inc: TC_V3): the lane-
+        # cooperative lowerings evaluate groups with all lanes of an instance and the LDS machine's context has no table
+        # pointer; the table shares the handle's diagnostic buffer with the profiling counters
+        if body == "ldsm" or lanes != 1:
+            raise ValueError("solverVerboseLevel >= 3 (tc_trace) is available on the one-thread-per-instance lowerings only "
+                             "(lanes=1, body='code' or 'interp'); got body=%r, lanes=%d" % (body, lanes))
+        if stats:
+            raise ValueError("solverVerboseLevel >= 3 and stats=%r share the handle's diagnostic buffer: build two classes" % (stats,))
     outdir = outdir or os.path.join(spec.folder, f"@{cls}")
     if not key_only:
         os.makedirs(outdir, exist_ok=True)
@@ -2192,7 +2206,11 @@ def build_class(spec, fp_contract="fast", arch="gfx950", opt="-O3", block=64, fo
         # (Relaxed branches are not a defect by themselves: the tile machine's dispatcher tc_interp is 440 KB with 83 of
         # them and passes every GPU parity test.  The check keeps the compiled walk inside the regime that has been
         # exercised; it is a conservative condition, not a proof of what faulted.)
-        big = _largest_function(so, "tcc_r")
+        try:
+            big = _largest_function(so, "tcc_r", arch)
+        except RuntimeError:
+            os.remove(so)                  # no library without its check (and none without its .stamp / .key / .flags)
+            raise
         if big[1] >= 120 * 1024:
             os.remove(so)
             raise RuntimeError(f"compiled LDS walk of {cls}: function {big[0]} is {big[1]} bytes -- beyond the reach of a "

@@ -383,11 +383,17 @@ def device_words(words, ranges, lo):
     w = list(words)
     done = set()
 
+    def off(row):
+        b = (row - lo) * ROW_BYTES
+        if not 0 <= b < 2 ** 31:            # every converted word, header words included: an offset that wrapped would
+            raise OverflowError("byte offset of a row outside [0, 2 GB)")     # silently address another row of the tile
+        return b
+
     def dst(k):
-        w[k] = (words[k] - lo) * ROW_BYTES
+        w[k] = off(words[k])
 
     def opd(k):
-        w[k] = ((words[k] >> 1) - lo) * ROW_BYTES | (words[k] & 1)
+        w[k] = off(words[k] >> 1) | (words[k] & 1)
 
     for rg in ranges:
         for start, end in rg:
@@ -432,8 +438,6 @@ def device_words(words, ranges, lo):
                 elif words[pc] != OP_BARRIER:
                     raise AssertionError(f"bad record width {K} at {pc}")
                 pc += ln
-    if any(x < 0 or x >= 2 ** 31 for k in done for x in w[k + 8:k + words[k + 6]]):
-        raise OverflowError("byte offset of a row outside [0, 2 GB)")
     return w
 
 

