@@ -536,7 +536,10 @@ def iteration_spread(it, variant, B, kernel_s, calib=None):
             out["ms_per_iteration_from"] = "one solve of the first %d instances (one per CU): %.2f ms / %d iterations of its slowest" % (
                 calib[2], calib[0] * 1e3, calib[1])
             out["straggler_floor_ms"] = hi * t_iter * 1e3
-            out["throughput_floor_ms"] = float(it.sum()) * t_iter * 1e3 / min(CUS, B)      # (one resident per CU)
+            res = calib[3] if len(calib) > 3 else 1            # workgroups of this class that fit a CU's LDS side by side
+            out["residents_per_cu"] = res
+            out["throughput_floor_ms"] = float(it.sum()) * t_iter * 1e3 / min(CUS * res, B)
+            out["straggler_position"] = float(int(np.argmax(it))) / max(len(it) - 1, 1)     # 0 = dispatched first, 1 = last
             out["batch_over_floor"] = kernel_s * 1e3 / max(out["straggler_floor_ms"], out["throughput_floor_ms"])
             out["tail_note"] = ("one instance per workgroup: batch >= max(straggler_floor_ms, throughput_floor_ms); the straggler "
                                 "starts when the workgroup dispatcher reaches it, which no launch order can know in advance")
@@ -825,7 +828,7 @@ def bench_config(args, R):
             oc.set(n, stacked[n][:Bc])
         oc.solve(**SOLVE)
         _, itc, tmc = oc.solve(**SOLVE)
-        calib = (float(tmc), int(np.asarray(itc).max()), Bc)
+        calib = (float(tmc), int(np.asarray(itc).max()), Bc, max(1, int(160 * 1024 // (8 * int(kw.get("lds_slots", 20000))))))
         oc.close()
         phase("per-iteration calibration")
     if rank == 0:

@@ -1728,7 +1728,8 @@ def _ldsc_functions(cs, W, chunk=96, depth=12, trace=False):
     return "".join(w)
 
 
-def emit_class_ldsm(spec, waves=4, stats=False, lds_slots=20000, fuse_chain=True, compiled=False, lds_stage=0, min_waves=0):
+def emit_class_ldsm(spec, waves=4, stats=False, lds_slots=20000, fuse_chain=True, compiled=False, lds_stage=0, min_waves=0,
+                    lds_split_min=0):
     """body="ldsm": ONE instance per workgroup of `waves` wavefronts, hot state in LDS, the tape as data whose
     records give every lane a different scalar instruction (csrc/tc_ldsm.hip.inc, ldsm_schedule.py).
     min_waves=k: the kernel is compiled for k wavefronts per SIMD (512 / k registers), so that as many workgroups as the LDS
@@ -1742,10 +1743,15 @@ def emit_class_ldsm(spec, waves=4, stats=False, lds_slots=20000, fuse_chain=True
         # the class walks a tape whose dependency groups are coarser than the reference's (ldsm_schedule.fused_tape: the
         # factorisation and the substitutions that read it as ONE level schedule; the groups one solve cannot tell apart
         # as one group); values are unchanged
-        T = lsch.fused_tape(T, spec.defines)
+        T = lsch.fused_tape(T, spec.defines, split_div=os.environ.get("TC_LDSM_SPLIT_DIV", "0") == "1")
     cls = spec.classname
     W = int(waves)
-    cs = lsch.class_stream(T, cls, spec.defines, W=W, lds_slots=lds_slots, stage=lds_stage)
+    # lds_split_min: long minima / maxima / sums of products with more terms than this are folded in two levels (default
+    # ldsm_schedule.SPLIT_MIN = 96).  mpc_dcmotor's 96-term cost row sat exactly on the default: one lane folded it alone, and
+    # the compiled walk requested the whole row at once -- 192 registers, spilled under the 248-register cap of `ldscs`
+    # (3.2 GB of scratch writes per launch); with 48 it is two independent lines of 50 + 46 terms (the reference's own
+    # statement split, instructionsTableUTHash.c:1003-1012): 19.9 -> 18.95 ms, bit-identical (profiles/r06_dcmotor_split_min.log)
+    cs = lsch.class_stream(T, cls, spec.defines, W=W, lds_slots=lds_slots, stage=lds_stage, split=int(lds_split_min) or True)
     L = cs["lowering"]
     addr = cs["addr"]
     nW = max(1, (T.nGroups + 63) // 64)
@@ -2096,7 +2102,7 @@ def build_class(spec, fp_contract="fast", arch="gfx950", opt="-O3", block=64, fo
                 recip=False, fast_div=False, inline_max=0, reg_budget=150, scratch="auto", body="code",
                 waves=1, fuse=False, static_clean=False, forward=False, rcache=0, lds_state=0, share=False,
                 branch_free_tails=True, exact=False, stg_blocks=0, lds_slots=20000, ilp=False, fw_window=0, sched_every=0,
-                try_flags=(), refresh_outputs=False, compiled=False, lds_stage=0, key_only=False):
+                try_flags=(), refresh_outputs=False, compiled=False, lds_stage=0, key_only=False, lds_split_min=0):
     """Emit <cls>.hip (+ <cls>.h, <cls>.tape) and compile lib<cls>.so with hipcc for gfx950.
     Mirrors the createGateway/compile step of cmex2optimizeCS.m:403-417.
 
@@ -2132,7 +2138,7 @@ def build_class(spec, fp_contract="fast", arch="gfx950", opt="-O3", block=64, fo
     kq.update(repr((cls, sorted(spec.defines.items()), [(n, tuple(sz)) for n, sz in spec.outputs], fp_contract, arch, opt, block,
                     stats, tag, tuple(extra_flags), roll, min_waves, lanes, recip, fast_div, inline_max, reg_budget, scratch,
                     body, waves, fuse, static_clean, forward, rcache, lds_state, share, branch_free_tails, exact, stg_blocks,
-                    lds_slots, ilp, fw_window, sched_every, tuple(tuple(a) if isinstance(a, (tuple, list)) else a for a in try_flags), refresh_outputs, compiled, lds_stage, os.environ.get("TC_LDS_PAD_SLOTS", ""), os.environ.get("TC_STG_BATCH", ""), os.environ.get("TC_LDSM_FUSE", ""), os.environ.get("TC_INTERP_FUSE", ""), os.environ.get("TC_INTERP_PAIRS", ""), os.environ.get("TC_FINE_LIVES", ""), os.environ.get("TC_INTERP_WIDE_MIN", ""), os.environ.get("TC_INTERP_L4_MIN", ""), os.environ.get("TC_LDSM_LOOP_MERGE", ""), os.environ.get("TC_LDSC_DEPTH", ""), os.environ.get("TC_LDSM_PACK_LOCALS", ""), os.environ.get("TC_LDSM_ROW_SKEW", ""), os.environ.get("TC_LDSM_LATE_LAST", ""), os.environ.get("TC_LDSM_PAD_PRODUCTS", ""), os.environ.get("TC_LDSM_MERGE_PRODUCTS", ""), os.environ.get("TC_LDSM_COLD_RANK", ""), os.environ.get("TC_LDSC_TWO_PHASE", ""), os.environ.get("TC_LDSC_SPLIT_HBM", ""), os.environ.get("TC_LDSC_SCHEDB", ""), os.environ.get("TC_LDSC_BYTES", ""), os.environ.get("TC_LDSC_WPE", ""), os.environ.get("TC_LDSM_STAGE", ""), os.environ.get("TC_LDSC_CHUNK", ""), os.environ.get("TC_WPE", ""),
+                    lds_slots, ilp, fw_window, sched_every, tuple(tuple(a) if isinstance(a, (tuple, list)) else a for a in try_flags), refresh_outputs, compiled, lds_stage, lds_split_min, os.environ.get("TC_LDS_PAD_SLOTS", ""), os.environ.get("TC_STG_BATCH", ""), os.environ.get("TC_LDSM_FUSE", ""), os.environ.get("TC_INTERP_FUSE", ""), os.environ.get("TC_INTERP_PAIRS", ""), os.environ.get("TC_FINE_LIVES", ""), os.environ.get("TC_INTERP_WIDE_MIN", ""), os.environ.get("TC_INTERP_L4_MIN", ""), os.environ.get("TC_LDSM_LOOP_MERGE", ""), os.environ.get("TC_LDSC_DEPTH", ""), os.environ.get("TC_LDSM_PACK_LOCALS", ""), os.environ.get("TC_LDSM_ROW_SKEW", ""), os.environ.get("TC_LDSM_LATE_LAST", ""), os.environ.get("TC_LDSM_PAD_PRODUCTS", ""), os.environ.get("TC_LDSM_MERGE_PRODUCTS", ""), os.environ.get("TC_LDSM_COLD_RANK", ""), os.environ.get("TC_LDSC_TWO_PHASE", ""), os.environ.get("TC_LDSC_SPLIT_HBM", ""), os.environ.get("TC_LDSC_SCHEDB", ""), os.environ.get("TC_LDSC_BYTES", ""), os.environ.get("TC_LDSC_WPE", ""), os.environ.get("TC_LDSM_STAGE", ""), os.environ.get("TC_LDSC_CHUNK", ""), os.environ.get("TC_WPE", ""), os.environ.get("TC_LDSM_SPLIT_MIN", ""), os.environ.get("TC_LDSM_SPLIT_DIV", ""), os.environ.get("TC_LDSM_SPLIT_DIV_MIN", ""), os.environ.get("TC_LDSM_DIV_NEST", ""),
                     os.environ.get("TC_SWEEP_UNROLL", ""))).encode())
     for f_ in sorted(os.listdir(HERE)):
         if f_.endswith(".py"):
@@ -2152,7 +2158,7 @@ def build_class(spec, fp_contract="fast", arch="gfx950", opt="-O3", block=64, fo
         if fp_contract != "off":
             raise ValueError("body='ldsm' is a bit-exact back-end: fp_contract='off'")
         src, L = emit_class_ldsm(spec, waves=waves, stats=stats, lds_slots=lds_slots,      # TC_LDSM_FUSE=0: no fused walk
-                                 compiled=bool(compiled), lds_stage=lds_stage, min_waves=min_waves)
+                                 compiled=bool(compiled), lds_stage=lds_stage, min_waves=min_waves, lds_split_min=lds_split_min)
     else:
       src, L = emit_class(spec, fp_contract=fp_contract, block=block, stats=stats, roll=roll,
                         min_waves=min_waves, lanes=lanes, recip=recip, fast_div=fast_div, inline_max=inline_max,

@@ -45,8 +45,11 @@ NLATE = 2              # late terms a FOLD record can compute itself (body rows 
 OP_COPY = 60
 OP_CLPTERM = 61       # (b < 0) ? -a/b : DBL_MAX  -- one term of I_clp
 OP_PROD3 = 62         # a * (b * c): a term of a dot one of whose factors is itself a product of the level before
+OP_PRODDN = 65        # (a / c) * ((b / c) * c): the same term when a and the product's first factor are the quotients N1 / D, N2 / D
+                      # of the level before (_div_nest): evaluated from N1, N2, D, one level earlier
+DN_SHIFT = 21          # aux bits 21-22 of a dot FOLD record: late term 0 / 1 is of the OP_PRODDN form (uniform over the record)
 F_MININF, F_MAXINF = 63, 64   # folds over one chunk of a long minimum / maximum: the chain starts from +inf / -inf
-SPLIT_MIN = 96        # a min / max / clp / long sum with more terms is folded in two levels (build_stream)
+SPLIT_MIN = 96        # a min / max / clp / long sum with more terms is folded in two levels (build_stream; TC_LDSM_SPLIT_MIN overrides)
 SPLIT_CHUNK = 32
 F_SUM = 3             # fold opcodes of K_FOLD records (the dot opcodes and I_sumprod keep their own number)
 STAGE = 2048          # staging slots for the terms of long instructions
@@ -102,6 +105,68 @@ def _nested_factor(T, opl, ost, g, ids):
     return None
 
 
+class _DN(list):
+    """operand words [N1, N2, D] of a term in the OP_PRODDN form (build_stream)"""
+
+
+def _div_nest(T, opl, ost, g, ids, k):
+    """The term a * v of a dot, v = p * q the plain product that _nested_factor chose (factor k), is a term of a symbolic
+    LDL' written with its divisions spelled out (split_div_tape): a = N1 / D and one factor of v is N2 / D with the other
+    factor D itself -- L(r,i) * (L(c,i) * D(i)) = (N1/D) * ((N2/D) * D).  -> (N1, N2, D), the three values the term can be
+    evaluated from ONE LEVEL EARLIER than from a, p, q (the divisions are done by the lane that needs the term: the same
+    roundings in the same order, a / D and p / D rounded as the I_div instructions round them), or None.
+    OFF unless TC_LDSM_DIV_NEST=1: measured on mpc_quadcopter (profiles/r06_quadcopter_div_nest.log) the walk has 12 % fewer
+    steps and is 8 % SLOWER -- two correctly rounded divisions on the critical path of every fold step cost more than the
+    steps they remove; bit-identical either way."""
+    if os.environ.get("TC_LDSM_DIV_NEST", "0") != "1":
+        return None
+    a, v = ids[1 - k], ids[k]
+    ty = T.types
+    if int(ty[a - 1]) != I.I_div or T.group[a] != g or not T.used[a]:
+        return None
+    n1, d = opl[ost[a - 1]:ost[a]]
+    pj = opl[ost[v - 1]:ost[v]]
+    for p_, q_ in ((pj[0], pj[1]), (pj[1], pj[0])):
+        if q_ == d and int(ty[p_ - 1]) == I.I_div and T.group[p_] == g and T.used[p_]:
+            n2, d2 = opl[ost[p_ - 1]:ost[p_]]
+            if d2 == d:
+                return n1, n2, d, (pj[0] == p_)          # last: the division is the FIRST factor of v = p * q (operand order)
+    return None
+
+
+def _dot_level(T, opl, ost, grp, lvl, g, ops, skip, ignore=None):
+    """level of a staged dot of group g with operands `ops` (the first `skip` are heads) from the levels of what it reads:
+    a factor that is a plain product of the group counts through ITS factors (nested product), a term of the form
+    (N1/D) * ((N2/D) * D) through N1, N2 and D (_div_nest).  ignore: an operand position left out (split_div_tape: the divisor)"""
+    l_ = 0
+    expand = set()
+    divn = {}
+    for q in range(skip, len(ops) - 1, 2):
+        k = _nested_factor(T, opl, ost, g, ops[q:q + 2])
+        if k is not None:
+            expand.add(q + k)
+            dn = _div_nest(T, opl, ost, g, ops[q:q + 2], k)
+            if dn is not None:                  # both operands of the pair are replaced by N1, N2, D
+                divn[q] = divn[q + 1] = dn[:3]
+    for q, j in enumerate(ops):
+        if q == ignore:
+            continue
+        if q in divn:
+            for jj in divn[q]:
+                if grp[jj] == g and lvl[jj] + 1 > l_:
+                    l_ = lvl[jj] + 1
+            continue
+        if grp[j] != g:
+            continue
+        if q in expand:
+            for jj in opl[ost[j - 1]:ost[j]]:
+                if grp[jj] == g and lvl[jj] + 1 > l_:
+                    l_ = lvl[jj] + 1
+        elif lvl[j] + 1 > l_:
+            l_ = lvl[j] + 1
+    return l_
+
+
 def stream_levels(T, nested=True):
     """Levels for the record stream.  As group_levels, except that a staged dot product (more than NSHORT operands)
     does not wait for a factor that is itself a plain product v = p*q of its group: the term a*v can be evaluated
@@ -119,22 +184,13 @@ def stream_levels(T, nested=True):
             op = int(T.types[i - 1])
             dot = nested and op in _DOTS and len(ops) > NSHORT
             skip = _DOT_SKIP.get(op, 0) if dot else 0
-            l_ = 0
-            expand = set()
             if dot:
-                for q in range(skip, len(ops) - 1, 2):
-                    k = _nested_factor(T, opl, ost, g, ops[q:q + 2])
-                    if k is not None:
-                        expand.add(q + k)
-            for q, j in enumerate(ops):
-                if grp[j] != g:
-                    continue
-                if q in expand:
-                    for jj in opl[ost[j - 1]:ost[j]]:
-                        if grp[jj] == g and lvl[jj] + 1 > l_:
-                            l_ = lvl[jj] + 1
-                elif lvl[j] + 1 > l_:
-                    l_ = lvl[j] + 1
+                l_ = _dot_level(T, opl, ost, grp, lvl, g, ops, skip)
+            else:
+                l_ = 0
+                for j in ops:
+                    if grp[j] == g and lvl[j] + 1 > l_:
+                        l_ = lvl[j] + 1
             lvl[i] = l_
             if l_ > mx:
                 mx = l_
@@ -285,10 +341,77 @@ def loop_classes(T, defines):
     return sets
 
 
-def fused_tape(T, defines):
+def split_div_tape(T, min_operands=NSHORT + 1):
+    """The tape with the long `(h0 - sum) / h1` (I_plus_minus_dot_div) and `(-sum) / h0` (I_minus_dot_div) whose DIVISOR is
+    what they wait for written as TWO instructions, the numerator (I_plus_minus_dot / I_minus_dot: the same chain, rounded
+    the same) and an I_div -- bit for bit the same values: the reference's statement rounds the numerator before it
+    divides (instructionsTableUTHash.c:1067-1108).
+
+    Why: in the symbolic LDL' (sparsity_ldl.m:161-222) L(r,c) = (A(r,c) - sum_i L(r,i) v_i) / D(c) waits for D(c), which is
+    itself a fold of column c's row that ends in the same late term -- two dependent fold steps per column.  The
+    numerator needs nothing that D(c) does not need as well: split, it is folded IN THE STEP of D(c) (other lanes, other
+    wavefronts), and the second step of the column is one short division record instead of a second row read, chain and
+    late term.  An instruction whose numerator is as late as its divisor is left alone (the split would cost it a
+    level).  Same dependency groups (T's own, merged ones included), entry points remapped; the new values are
+    group-local."""
+    n = T.n
+    ost, opl = T.opStart.tolist(), T.ops.tolist()
+    pst, prl = T.parStart.tolist(), T.pars.tolist()
+    ty = T.types.tolist()
+    grp = T.group.tolist()
+    lvl, _ = stream_levels(T, True)
+
+    def numerator_level(i, g, ops, skip, div_pos):
+        return _dot_level(T, opl, ost, grp, lvl, g, ops, skip, ignore=div_pos)
+    new = [0] * (n + 1)
+    types2, ops2, os2, pars2, ps2 = [], [], [0], [], [0]
+    extra = {}                                    # group -> new ids of the numerators
+
+    def put(t, o, p):
+        types2.append(t)
+        ops2.extend(o)
+        os2.append(len(ops2))
+        pars2.extend(p)
+        ps2.append(len(pars2))
+        return len(types2)
+    for i in range(1, n + 1):
+        t = ty[i - 1]
+        old_ops = opl[ost[i - 1]:ost[i]]
+        o = [new[j] for j in old_ops]
+        p = prl[pst[i - 1]:pst[i]]
+        # (the numerator must stay a staged dot -- more than NSHORT operands -- or it loses its nested late terms)
+        if T.used[i] and grp[i] and len(o) >= max(min_operands, NSHORT + 2) and t in (I.I_plus_minus_dot_div, I.I_minus_dot_div):
+            dpos = 1 if t == I.I_plus_minus_dot_div else 0
+            if numerator_level(i, grp[i], old_ops, _DOT_SKIP[t], dpos) < lvl[i]:
+                if t == I.I_plus_minus_dot_div:
+                    num = put(I.I_plus_minus_dot, [o[0]] + o[2:], p)
+                else:
+                    num = put(I.I_minus_dot, o[1:], p)
+                new[i] = put(I.I_div, [num, o[dpos]], [])
+                extra.setdefault(grp[i], []).append(num)
+                continue
+        new[i] = put(t, o, p)
+    if not extra:
+        return T
+    rm = np.asarray(new, dtype=np.int64)
+    sets = [dict(name=e["name"], varname=e["varname"], size=e["size"], ins=rm[e["ins"]], external=e["external"]) for e in T.sets]
+    gets = [dict(name=e["name"], outputs=[dict(name=o_["name"], size=o_["size"], ins=rm[o_["ins"]]) for o_ in e["outputs"]])
+            for e in T.gets]
+    copies = [dict(name=e["name"], dst=rm[e["dst"]], src=rm[e["src"]]) for e in T.copies]
+    merge = [np.concatenate([rm[members], np.asarray(extra.get(g, []), dtype=np.int64)]) for g, members in enumerate(T.groups, 1)]
+    from .csparse import Tape
+    return Tape.from_instructions(np.asarray(types2, dtype=np.int32), np.asarray(os2, dtype=np.int64),
+                                  np.asarray(ops2, dtype=np.int64), np.asarray(ps2, dtype=np.int64),
+                                  np.asarray(pars2, dtype=np.float64), sets, gets, copies, T.defines, ldl_stats=T.ldl_stats,
+                                  merge=merge)
+
+
+def fused_tape(T, defines, split_div=False):
     """the tape the LDS machine walks: the reference's instructions and entry points, coarser dependency groups --
     factorisation + substitutions as one level schedule (fusion_sets), then the groups one solve cannot tell apart
-    (loop_classes).  Values are unchanged.  TC_LDSM_FUSE=0 / TC_LDSM_LOOP_MERGE=0 switch the steps off."""
+    (loop_classes).  Values are unchanged.  TC_LDSM_FUSE=0 / TC_LDSM_LOOP_MERGE=0 switch the steps off.
+    split_div: split_div_tape afterwards (hip_emitter.emit_class_ldsm asks for it when TC_LDSM_SPLIT_DIV=1; off by default:
+    no gain by itself -- a step with one short division record costs what a fold step costs -- and slower with _div_nest)."""
     if os.environ.get("TC_LDSM_FUSE", "1") != "0":
         fs = fusion_sets(T)
         if fs:
@@ -300,6 +423,14 @@ def fused_tape(T, defines):
                 # stay alone as sets of one, or the first step's merge would be undone)
                 taken = {g for S in cs for g in S}
                 T = T.merged(cs + [[g] for g in range(1, T.nGroups + 1) if g not in taken])
+    if split_div:
+        # (levels are those of the merged groups.  Repeated: once the divisions of a column are instructions of their own,
+        # the terms built on them move up a level (_div_nest), and more numerators turn out to be earlier than their divisor)
+        for _ in range(8):
+            T2 = split_div_tape(T, int(os.environ.get("TC_LDSM_SPLIT_DIV_MIN", NSHORT + 1)))
+            if T2 is T:
+                break
+            T = T2
     return T
 
 
@@ -392,7 +523,15 @@ def assign_slots(T, defines, lds_slots=20000, stage=STAGE, pack_locals=None):
                 if not T.used[i]:
                     continue
                 li = slvl[i]
-                for j in opl[ost[i - 1]:ost[i]]:
+                ops_i = opl[ost[i - 1]:ost[i]]
+                if int(T.types[i - 1]) in _DOTS and len(ops_i) > NSHORT:      # ... or N1, N2, D of a term (_div_nest)
+                    for q in range(_DOT_SKIP[int(T.types[i - 1])], len(ops_i) - 1, 2):
+                        k_ = _nested_factor(T, opl, ost, g, ops_i[q:q + 2])
+                        dn_ = _div_nest(T, opl, ost, g, ops_i[q:q + 2], k_) if k_ is not None else None
+                        for jj in (dn_[:3] if dn_ else ()):
+                            if jj in los and li > last[jj]:
+                                last[jj] = li
+                for j in ops_i:
                     if j in los:
                         if li > last[j]:
                             last[j] = li
@@ -604,7 +743,8 @@ _TERM = {  # long instruction -> (term opcode, operands per term, fold opcode); 
 
 def _split_chunk(fop, aux, nterm, split=True):
     """chunk length of a two-level fold, or 0"""
-    if not split or fop not in _SPLIT or nterm <= SPLIT_MIN:
+    # split: False (never), True (more than SPLIT_MIN terms) or the threshold itself (build_class(lds_split_min=...))
+    if not split or fop not in _SPLIT or nterm <= int(os.environ.get("TC_LDSM_SPLIT_MIN", SPLIT_MIN if split is True else split)):
         return 0
     per = -(-100 // max(aux, 1)) if fop == I.I_sumprod else SPLIT_CHUNK
     return per if nterm > per else 0
@@ -812,14 +952,18 @@ def build_stream(T, addr, nLds, W=1, stage_base=None, nStage=0, hoist=True, pads
                             # a factor that is a plain product of the level before (or later: stream_levels did not
                             # wait for it) is expanded: a*v -> a*(p*q), the same two roundings in the same order
                             k = _nested_factor(T, opl, ost, g, ids)
-                            if k is not None and prev is not None and lvl[ids[k]] >= prev:
+                            if k is not None and lvl[ids[k]] >= (prev if prev is not None else l_):
+                                dn = _div_nest(T, opl, ost, g, ids, k)
                                 pj = opl[ost[ids[k] - 1]:ost[ids[k]]]
                                 ids = [ids[1 - k]] + list(pj)
                                 tw = [tw[1 - k]] + [int(addr[j]) * 2 for j in pj]
+                                if dn is not None and any(T.group[j] == g and T.used[j] and lvl[j] >= l_ for j in ids):
+                                    # the quotients themselves are values of THIS level (stream_levels counted the term
+                                    # through N1, N2, D): the folding lane divides
+                                    ids = list(dn[:3])
+                                    tw = _DN(int(addr[j]) * 2 for j in ids)
                                 if min(tw) < 0:
                                     raise AssertionError("nested product: operand without storage")
-                            elif k is not None and prev is None and lvl[ids[k]] >= l_:
-                                raise AssertionError("nested product at the first level of a group")
                         tl.append(tw)
                         late.append(prev is not None and any(T.group[j] == g and T.used[j] and lvl[j] >= prev for j in ids))
                         if any(T.group[j] == g and T.used[j] and lvl[j] >= l_ for j in ids):
@@ -872,8 +1016,15 @@ def build_stream(T, addr, nLds, W=1, stage_base=None, nStage=0, hoist=True, pads
 
         def term_key(s_, tw):
             if s_["top"] == "prod":
+                if isinstance(tw, _DN):
+                    return (OP_PRODDN, 3, 0)
                 return (OP_PROD3, 3, 0) if len(tw) == 3 and s_["tn"] == 2 else (I.I_sumprod, s_["tn"], s_["tn"])
             return (s_["top"], s_["tn"], 0)
+
+        def dn_bits(s_):
+            """which of the (at most NLATE) inline late terms of a hoisted row are of the OP_PRODDN form"""
+            lt = [q for q, x in enumerate(s_["late"]) if x]
+            return sum(1 << q for q in range(min(len(lt), NLATE)) if isinstance(s_["terms"][lt[q]], _DN))
 
         def pad_row(terms, fop, base, n_, like=None):
             """the operation's identity (-0.0 for sums, +inf for minima, -inf for maxima) into the slots between the
@@ -921,8 +1072,8 @@ def build_stream(T, addr, nLds, W=1, stage_base=None, nStage=0, hoist=True, pads
             if lv["hoist"]:
                 folds = {}
                 for s_ in staged:
-                    folds.setdefault((s_["fop"], 0, s_["aux"] | (LATE_LAST if late_last(s_) else 0)), []).append(
-                        fold_item(s_, s_["base"], True))
+                    folds.setdefault((s_["fop"], 0, s_["aux"] | (LATE_LAST if late_last(s_) else 0) | (dn_bits(s_) << DN_SHIFT)),
+                                     []).append(fold_item(s_, s_["base"], True))
                 for key, items in folds.items():
                     folds[key] = sorted(items, key=lambda it: -it[1][0])
                 emit(recs + cut(folds, K_FOLD, FOLD_COST) + ahead_next)

@@ -64,6 +64,9 @@ def _term(op, aux, v, sg):
     if op == lsch.OP_PROD3:
         with np.errstate(all="ignore"):
             return v[0] * (v[1] * v[2])
+    if op == lsch.OP_PRODDN:
+        with np.errstate(all="ignore"):
+            return (v[0] / v[2]) * ((v[1] / v[2]) * v[2])
     if op == lsch.OP_CLPTERM:
         with np.errstate(all="ignore"):
             return -v[0] / v[1] if v[1] < 0 else f64(np.finfo(float).max)
@@ -119,14 +122,19 @@ class Machine:
                         for t in range(nl[q]):                  # a * (b * c); c = the slot holding 1.0 for a plain product
                             pos, wa, wb, wc = (rows(6 + 4 * t + j)[q] for j in range(4))
                             with np.errstate(all="ignore"):
-                                if llast:
-                                    late[q].append(m[wa >> 1] * (m[wb >> 1] * m[wc >> 1]))
+                                xa, xb, xc = m[wa >> 1], m[wb >> 1], m[wc >> 1]
+                                if op in lsch._DOT_SKIP and (aux >> (lsch.DN_SHIFT + t)) & 1:      # OP_PRODDN form
+                                    val = (xa / xc) * ((xb / xc) * xc)
                                 else:
-                                    m[base[q] + pos] = m[wa >> 1] * (m[wb >> 1] * m[wc >> 1])
+                                    val = xa * (xb * xc)
+                                if llast:
+                                    late[q].append(val)
+                                else:
+                                    m[base[q] + pos] = val
                 for q in range(cnt):
                     # a padded row (ordered sums) is added up to the next multiple of 8: the pads must hold -0.0
                     nrow = -(-ln[q] // 8) * 8 if flags & lsch.F_PADDED else ln[q]
-                    res.append(_fold(op, aux & ~lsch.LATE_LAST if llast else aux,
+                    res.append(_fold(op, (aux & ~lsch.LATE_LAST if llast else aux) & ~(3 << lsch.DN_SHIFT) if op in lsch._DOT_SKIP else aux,
                                      [m[base[q] + k] for k in range(nrow)] + late[q], m[h0[q] >> 1], m[h1[q] >> 1]))
             else:
                 ln = rows(1)
@@ -173,9 +181,9 @@ class Machine:
 def _check(spec, data, tape_oracle, args, W=1, lds_slots=20000, stream_kw=None, fuse=False):
     T, c, D = spec.tape, spec.classname, spec.defines
     o = tape_oracle(T, c)                    # the oracle always walks the reference's partition into groups
-    if fuse == "loop":                       # ... the machine the coarser one of hip_emitter.emit_class_ldsm(fuse_chain=True):
-        T = lsch.fused_tape(T, D)            # factor + solves, then the groups one solve cannot tell apart
-        assert T.nGroups < spec.tape.nGroups
+    if fuse in ("loop", "loop+split"):       # ... the machine the coarser one of hip_emitter.emit_class_ldsm(fuse_chain=True):
+        T = lsch.fused_tape(T, D, split_div=fuse == "loop+split")      # factor + solves, then the groups one solve cannot tell
+        assert T.nGroups < spec.tape.nGroups      # apart (+split: the long (h0 - sum) / D(c) as numerator + division, TC_LDSM_SPLIT_DIV=1)
     elif fuse:                               # (only the first step)
         fs = lsch.fusion_sets(T, min_gain=32 if fuse is True else int(fuse))
         assert fs, "nothing to fuse on this tape"
@@ -461,3 +469,66 @@ def test_ldsm_stream_small_quadcopter_loop_merged(native_built, tape_oracle, tmp
     from tenscalc_amd.problems.mpc_quadcopter import SOLVE_ARGS, mpc_quadcopter, quadcopter_data
     spec = mpc_quadcopter(T=8, classname="tmp_quadcopter8", folder=str(tmp_path))
     _check(spec, quadcopter_data(2, T=8), tape_oracle, SOLVE_ARGS, W=4, fuse="loop")
+
+
+def test_split_div_tape_keeps_values_levels_and_groups(native_built, tape_oracle, tmp_path, monkeypatch):
+    """ldsm_schedule.split_div_tape on a factorisation with long rows (mpc_quadcopter, T = 20): every split instruction is a
+    division whose numerator is the same chain; the dependency groups and their level counts are those of the tape it
+    was given; an oracle walking the REWRITTEN tape returns the outputs of the original bit for bit"""
+    from tenscalc_amd.problems.mpc_quadcopter import SOLVE_ARGS, mpc_quadcopter, quadcopter_data
+    spec = mpc_quadcopter(T=20, classname="tmp_quadcopter20", folder=str(tmp_path))
+    T1 = lsch.fused_tape(spec.tape, spec.defines)
+    T2 = lsch.split_div_tape(T1)
+    nsplit = T2.n - T1.n
+    assert nsplit > 50 and T2.nGroups == T1.nGroups
+    # levels: never more than before (an instruction is split only where its divisor is what it waits for), and fewer in the
+    # factorisation -- with the quotients spelled out, the terms built on them are evaluated from the numerators and the
+    # pivot one level earlier (ldsm_schedule._div_nest): one fold step per column instead of two
+    n1 = lsch.stream_levels(T1)[1]
+    assert lsch.stream_levels(T2)[1] == n1                     # the split alone keeps every level
+    monkeypatch.setenv("TC_LDSM_DIV_NEST", "1")
+    n2 = lsch.stream_levels(T2)[1]
+    assert all(b_ <= a_ for a_, b_ in zip(n1, n2)) and sum(n2) <= sum(n1) - 10
+    monkeypatch.delenv("TC_LDSM_DIV_NEST")
+    assert [len(m_) for m_ in T2.groups] != [len(m_) for m_ in T1.groups]           # the numerators joined their groups
+    assert int((T2.types == I.I_div).sum()) - int((T1.types == I.I_div).sum()) == nsplit
+    d = quadcopter_data(3, T=20)
+    c = spec.classname
+    outs = []
+    for T in (spec.tape, T2):
+        o = tape_oracle(T, c)
+        for nm, _ in spec.parameters + spec.variables:
+            o.set("%s_set_%s" % (c, nm), d[nm])
+        st, it = o.solve(SOLVE_ARGS["mu0"], SOLVE_ARGS["maxIter"], -1, SOLVE_ARGS["addEye2Hessian"])
+        outs.append((st, it, o.get(c + "_getOutputs")))
+    assert outs[0][:2] == outs[1][:2] and outs[0][0] == 0
+    assert np.array_equal(outs[0][2], outs[1][2])
+
+
+def test_ldsm_stream_quadcopter20_div_nested_terms(native_built, tape_oracle, tmp_path, monkeypatch):
+    """a factorisation with long rows (T = 20) on the tape the emitter walks: the stream holds late terms of the
+    (N1/D) * ((N2/D) * D) form -- inline in fold records (aux bits DN_SHIFT..) -- and the model of the walk still reproduces
+    every get of the oracle, which evaluates the ORIGINAL tape"""
+    from tenscalc_amd.problems.mpc_quadcopter import SOLVE_ARGS, mpc_quadcopter, quadcopter_data
+    monkeypatch.setenv("TC_LDSM_DIV_NEST", "1")          # (an option of the LDS machine, off by default: fewer steps, slower ones)
+    spec = mpc_quadcopter(T=20, classname="tmp_quadcopter20", folder=str(tmp_path))
+    cs = _check(spec, quadcopter_data(2, T=20), tape_oracle, SOLVE_ARGS, W=4, fuse="loop+split")
+    hd = np.asarray(cs["headers"]).reshape(-1, 8)
+    folds = hd[(hd[:, 0] >> 8) == lsch.K_FOLD]
+    dots = folds[np.isin(folds[:, 0] & 255, list(lsch._DOT_SKIP))]
+    assert ((dots[:, 2] >> lsch.DN_SHIFT) & 3).any(), "no fold record with a division-nested late term"
+
+
+def test_ldsm_stream_dcmotor_as_benchmarked(native_built, tape_oracle, tmp_path):
+    """the stream of bench.py's mpc_dcmotor class (`ldscs`: two wavefronts, a quarter of a CU's LDS, 512 staging slots, long
+    reductions folded in two levels from 48 terms on -- the 96-term cost row as the reference's two statement lines)"""
+    import __graft_entry__ as g
+    from tenscalc_amd.problems.mpc_dcmotor import SOLVE_ARGS, dcmotor_data, mpc_dcmotor
+    kw = g.VARIANT_KW["ldscs"]
+    spec = mpc_dcmotor(folder=str(tmp_path))
+    cs = _check(spec, dcmotor_data(9), tape_oracle, SOLVE_ARGS, W=kw["waves"], lds_slots=kw["lds_slots"], fuse="loop",
+                stream_kw=dict(stage=kw["lds_stage"], split=kw["lds_split_min"]))
+    hd = np.asarray(cs["headers"]).reshape(-1, 8)
+    folds = hd[(hd[:, 0] >> 8) == lsch.K_FOLD]
+    sp = folds[(folds[:, 0] & 255) == I.I_sumprod]
+    assert len(sp) and sp[:, 1].max() <= 56 and cs["nCold"] == 0     # no sum of products longer than a statement line; state in LDS
