@@ -230,6 +230,9 @@ def main():
                          "CU -- parity class solver-tolerance; w8h / regs / regsl: other lowerings of the hoisted tape")
     ap.add_argument("--cpu-sample", type=int, default=int(os.environ.get("TC_CPU_SAMPLE", "65536")))
     ap.add_argument("--no-cpu", action="store_true")
+    ap.add_argument("--no-calib", action="store_true",
+                    help="--config with an lds* variant: skip the extra solve of <= 256 instances that measures the time of one "
+                         "Newton iteration of one instance (profiling runs: every launch of the kernel is then a full batch)")
     ap.add_argument("--no-configs", action="store_true",
                     help="default N=1 sls run: do not attach the short runs of BASELINE configs[2..4] under \"configs\"")
     ap.add_argument("--per-step-events", action="store_true",
@@ -819,7 +822,7 @@ def bench_config(args, R):
     phase("warm-up + timed steps")
     out = None
     calib = None
-    if rank == 0 and not standin and variant.startswith("lds") and P == 1:
+    if rank == 0 and not standin and variant.startswith("lds") and P == 1 and not getattr(args, "no_calib", False):
         # the time of ONE Newton iteration of ONE instance on this back-end, measured: the first <= 256 instances, one per
         # CU, in a batch of their own -- its time is its slowest instance's (see iteration_spread)
         Bc = min(B, 256)

@@ -39,7 +39,7 @@ def _prelude(L, T, storage):
             "#include <math.h>\n#include <float.h>\n#include <stdint.h>\n#include <string.h>\n"
             f"{storage} double m[{max(1, L.nPriv)}];\n{storage} double S[{max(1, L.nExt)}];\n"
             f"{storage} unsigned char groupStatus[{T.nGroups + 1}];\n"
-            "#define MM(k) (m[k])\n#define SX(k) (S[k])\n#define TC_DIV(x, d) ((x) / (d))\n#define TC_NUM(x, d) (x)\n#define TC_POW_NEG(x, y) pow((x), (y))\n"
+            "#define MM(k) (m[k])\n#define SX(k) (S[k])\n#define TC_DIV(x, d) ((x) / (d))\n#define TC_NUM(x, d) (x)\n#define TC_POW_NEG(x, y) pow((x), (y))\n#define TC_EXP(x) exp(x)\n#define TC_LOG(x) log(x)\n#define TC_SIN(x) sin(x)\n#define TC_COS(x) cos(x)\n#define TC_ATAN(x) atan(x)\n"
             "static inline double tc_min(double a, double x) { return (a > x) ? x : a; }\n"
             "static inline double tc_max(double a, double x) { return (a < x) ? x : a; }\n"
             "static inline double tc_clp(double a, double x, double dx) { if (dx < 0) { const double t = -x / dx; if (a > t) a = t; } return a; }\n")

@@ -6,9 +6,9 @@ set -u
 ROUND=${1:-r05}; CFG=${2:-dcmotor}; VAR=${3:-ldscs}; BATCH=${4:-0}
 R=$(pwd); OUT=$R/gpurun_out/sq_${ROUND}_${CFG}_${VAR}; mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-rocprofv3 --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_IFETCH --output-format csv -d $OUT/pmc_sq -- python3 $R/bench.py --config $CFG --variant $VAR --batch $BATCH --steps 2 --warmup 1 --no-cpu > $OUT/pmc_sq.log 2>&1
-rocprofv3 --pmc SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_INST_LDS SQ_INSTS_VMEM SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_BUSY_CYCLES GRBM_GUI_ACTIVE --output-format csv -d $OUT/pmc_sq2 -- python3 $R/bench.py --config $CFG --variant $VAR --batch $BATCH --steps 2 --warmup 1 --no-cpu > $OUT/pmc_sq2.log 2>&1
-rocprofv3 --pmc SQ_IFETCH_LEVEL SQ_INST_LEVEL_LDS SQ_INST_LEVEL_VMEM SQ_ACTIVE_INST_SCA SQ_ACTIVE_INST_MISC SQ_INSTS_SMEM SQ_WAVES SQ_INSTS_BRANCH --output-format csv -d $OUT/pmc_sq3 -- python3 $R/bench.py --config $CFG --variant $VAR --batch $BATCH --steps 2 --warmup 1 --no-cpu > $OUT/pmc_sq3.log 2>&1
+rocprofv3 --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_IFETCH --output-format csv -d $OUT/pmc_sq -- python3 $R/bench.py --config $CFG --variant $VAR --batch $BATCH --steps 2 --warmup 1 --no-cpu --no-calib > $OUT/pmc_sq.log 2>&1
+rocprofv3 --pmc SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_INST_LDS SQ_INSTS_VMEM SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_BUSY_CYCLES GRBM_GUI_ACTIVE --output-format csv -d $OUT/pmc_sq2 -- python3 $R/bench.py --config $CFG --variant $VAR --batch $BATCH --steps 2 --warmup 1 --no-cpu --no-calib > $OUT/pmc_sq2.log 2>&1
+rocprofv3 --pmc SQ_IFETCH_LEVEL SQ_INST_LEVEL_LDS SQ_INST_LEVEL_VMEM SQ_ACTIVE_INST_SCA SQ_ACTIVE_INST_MISC SQ_INSTS_SMEM SQ_WAVES SQ_INSTS_BRANCH --output-format csv -d $OUT/pmc_sq3 -- python3 $R/bench.py --config $CFG --variant $VAR --batch $BATCH --steps 2 --warmup 1 --no-cpu --no-calib > $OUT/pmc_sq3.log 2>&1
 cd $R && python3 - "$OUT" <<'PY'
 import csv, glob, sys, collections
 out = sys.argv[1]

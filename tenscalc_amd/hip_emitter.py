@@ -35,15 +35,15 @@ INCLUDE = os.path.join(os.path.dirname(HERE), "include")
 MAX_TERMS_PERLINE = 100  # instructionsTableUTHash.c:173
 
 _UNARY = {
-    I.I_exp: "exp({0})", I.I_log: "log({0})", I.I_cos: "cos({0})", I.I_minus_cos: "-cos({0})",
-    I.I_sin: "sin({0})", I.I_minus_sin: "-sin({0})", I.I_round: "round({0})",
+    I.I_exp: "TC_EXP({0})", I.I_log: "TC_LOG({0})", I.I_cos: "TC_COS({0})", I.I_minus_cos: "-TC_COS({0})",
+    I.I_sin: "TC_SIN({0})", I.I_minus_sin: "-TC_SIN({0})", I.I_round: "round({0})",
     I.I_ceil: "ceil({0})", I.I_floor: "floor({0})", I.I_abs: "fabs({0})",
     I.I_sign: "(({0}>=0)?1.0:-1.0)", I.I_sqrt: "sqrt({0})", I.I_Dsqrt: ".5*TC_POW_NEG({0},-.5)",
     I.I_DDsqrt: "-.25*TC_POW_NEG({0},-1.5)", I.I_sqr: "{0}*{0}", I.I_2times: "2*{0}", I.I_2: "2.0",
-    I.I_cube: "{0}*{0}*{0}", I.I_3sqr: "3*{0}*{0}", I.I_6times: "6*{0}", I.I_atan: "atan({0})",
+    I.I_cube: "{0}*{0}*{0}", I.I_3sqr: "3*{0}*{0}", I.I_6times: "6*{0}", I.I_atan: "TC_ATAN({0})",
     I.I_Datan: "1/(1+{0}*{0})", I.I_DDatan: "-2*{0}/(1+{0}*{0})/(1+{0}*{0})",
-    I.I_srelu: "log(1+exp({0}))", I.I_dsrelu: "1/(1+exp(-{0}))",
-    I.I_ddsrelu: "1/(2+exp(-{0})+exp({0}))", I.I_relu: "(({0}>0)?{0}:0.0)",
+    I.I_srelu: "TC_LOG(1+TC_EXP({0}))", I.I_dsrelu: "1/(1+TC_EXP(-{0}))",
+    I.I_ddsrelu: "1/(2+TC_EXP(-{0})+TC_EXP({0}))", I.I_relu: "(({0}>0)?{0}:0.0)",
     I.I_heaviside: "(({0}>0)?1.0:0.0)", I.I_inv: "TC_DIV(1.0,{0})", I.I_minus_inv_sqr: "-1/({0}*{0})",
     I.I_2_inv_cube: "2/({0}*{0}*{0})",
 }
@@ -796,6 +796,9 @@ class Printer:
         if typ == I.I_zero:
             return "0.0"
         if typ == I.I_componentwise:      # the reference prints the C text verbatim with m[operand] in the hole (:1333-1345)
+            eq = I.componentwise_opcode(par)      # a plain call of a function the ISA has an opcode for: that opcode's code,
+            if eq in _UNARY:                      # so that exp / log / pow are the HOST libm's here too (csrc/tc_pow.hip.inc)
+                return "(" + _UNARY[eq].format("(" + r[0] + ")") + ")"
             return "(" + I.componentwise_text(par).replace("%s", "(" + r[0] + ")") + ")"
         if typ in _UNARY:
             return _UNARY[typ].format(r[0] if r else "")

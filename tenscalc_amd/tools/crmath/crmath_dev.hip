@@ -27,3 +27,24 @@ extern "C" int crm_dev_eval(const double *x, double *a, double *b, double *c, do
   for (int k = 0; k < 4; k++) (void)hipFree(o[k]);
   return rc;
 }
+
+// the libm functions as the device evaluators compute them (TC_EXP .. TC_ATAN of csrc/tc_pow.hip.inc):
+// which = 0 exp, 1 log, 2 sin, 3 cos, 4 atan
+__global__ void crm_unary_kernel(int which, const double *x, double *y, long n) {
+  const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) y[i] = which == 0 ? TC_EXP(x[i]) : which == 1 ? TC_LOG(x[i]) : which == 2 ? TC_SIN(x[i]) : which == 3 ? TC_COS(x[i]) : TC_ATAN(x[i]);
+}
+extern "C" int crm_dev_unary(int which, const double *x, double *y, long n) {
+  double *dx = nullptr, *dy = nullptr;
+  int rc = (int)hipMalloc(&dx, 8 * n);
+  if (!rc) rc = (int)hipMalloc(&dy, 8 * n);
+  if (!rc) rc = (int)hipMemcpy(dx, x, 8 * n, hipMemcpyHostToDevice);
+  if (!rc) {
+    hipLaunchKernelGGL(crm_unary_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, 0, which, dx, dy, n);
+    rc = (int)hipDeviceSynchronize();
+  }
+  if (!rc) rc = (int)hipMemcpy(y, dy, 8 * n, hipMemcpyDeviceToHost);
+  (void)hipFree(dx);
+  (void)hipFree(dy);
+  return rc;
+}

@@ -28,3 +28,13 @@ void half_eval(const double *x, double *emul, double *libm, long n) {
 void glibc_emul_eval(const double *x, double *rs, double *rs3, long n) {
   for (long i = 0; i < n; i++) { rs[i] = tc_glibc_pow_negfrac(x[i], -.5); rs3[i] = tc_glibc_pow_negfrac(x[i], -1.5); }
 }
+
+/* exp / log (and, when restated, further unary functions) of csrc/tc_glibcpow.hip.inc next to this host's libm:
+ * which = 0 exp, 1 log, 2 sin, 3 cos, 4 atan */
+void unary_emul_eval(int which, const double *x, double *y, long n) {
+  for (long i = 0; i < n; i++)
+    y[i] = which == 0 ? tc_glibc_exp(x[i]) : which == 1 ? tc_glibc_log(x[i]) : which == 2 ? tc_glibc_sin(x[i]) : which == 3 ? tc_glibc_cos(x[i]) : tc_glibc_atan(x[i]);
+}
+void unary_libm_eval(int which, const double *x, double *y, long n) {
+  for (long i = 0; i < n; i++) y[i] = which == 0 ? exp(x[i]) : which == 1 ? log(x[i]) : which == 2 ? sin(x[i]) : which == 3 ? cos(x[i]) : atan(x[i]);
+}

@@ -128,3 +128,62 @@ def test_device_pow_is_the_hosts_pow_bit_for_bit():
     assert np.array_equal(o[2], ca, equal_nan=True)
     _, half = _eval(L.half_eval, x)
     assert np.array_equal(o[3], half, equal_nan=True)          # device TC_POW_HALF == this host's pow(x,.5)
+
+
+def _unary(f, which, x):
+    x = np.ascontiguousarray(x)
+    y = np.empty_like(x)
+    dp = ctypes.POINTER(ctypes.c_double)
+    rc = f(ctypes.c_int(which), x.ctypes.data_as(dp), y.ctypes.data_as(dp), ctypes.c_long(x.size))
+    assert not (rc if f.__name__.startswith("crm_dev") else 0)          # (the host harness returns nothing)
+    return y
+
+
+def _libm_arguments(seed, n):
+    """arguments for exp, log, sin, cos, atan: every branch of glibc's routines, the branch boundaries, special values"""
+    r = np.random.RandomState(seed)
+    sgn = lambda k: r.choice([-1.0, 1.0], k)           # noqa: E731
+    xe = np.concatenate([r.uniform(-750, 710, n), r.normal(0, 1, n // 2), r.uniform(-1e-3, 1e-3, n // 8),
+                         2.0 ** r.uniform(-1074, 10, n // 8) * sgn(n // 8),
+                         np.array([0.0, -0.0, np.inf, -np.inf, np.nan, 709.78, 709.79, 710.0, -708.4, -745.13, -745.14, -746.0, 1024.0,
+                                   -1024.0, 1e300, -1e300, 5e-324, 1.0, -1.0, 2.0 ** -54, 2.0 ** -55, 511.9, 512.0, -512.0])])
+    xl = np.concatenate([2.0 ** r.uniform(-1074, 1023, n), r.uniform(0.9, 1.1, n // 2), r.uniform(0, 4, n // 2),
+                         1 + r.uniform(-2.0 ** -4, 2.0 ** -4, n // 4),
+                         np.array([0.0, -0.0, np.inf, -np.inf, np.nan, 1.0, -1.0, 5e-324, 2.2250738585072014e-308,
+                                   1.7976931348623157e308, 0.9375, 1.0644, 1.0645, 1.06445, 1.064697265625, -3e-320])])
+    # sin / cos: Taylor (< 0.126), table (< 0.855469), pi/2 - x (< 2.426265), reduce_sincos (< 105414350), __branred beyond
+    xt = np.concatenate([r.uniform(-0.126, 0.126, n // 4), r.uniform(-0.9, 0.9, n // 2), r.uniform(-2.5, 2.5, n // 2),
+                         r.uniform(-100, 100, n // 2), r.uniform(-1.05e8, 1.05e8, n // 2), 2.0 ** r.uniform(-60, 26, n // 4) * sgn(n // 4),
+                         r.uniform(1.05e8, 1e12, n // 4) * sgn(n // 4), 2.0 ** r.uniform(26.7, 1023.9, n // 2) * sgn(n // 2),
+                         np.array([0.0, -0.0, np.inf, -np.inf, np.nan, 0.126, 0.855469, 2.426265, 105414349.0, 105414350.0, 105414357.85,
+                                   1e-300, 5e-324, np.pi, np.pi / 2, -np.pi / 2, 0.7853981633974483, 1e22, 1.7976931348623157e308,
+                                   -1.7976931348623157e308, 2.0 ** 1000])])
+    # atan: polynomial (< 1/16), table (< 1), through 1/x (< 16), pi/2 - 1/x (< 5.8e15), +-pi/2
+    xa = np.concatenate([r.uniform(-1 / 16, 1 / 16, n // 4), r.uniform(-1, 1, n // 2), r.uniform(-16, 16, n // 2), r.uniform(-1000, 1000, n // 4),
+                         2.0 ** r.uniform(-1074, 1023, n // 2) * sgn(n // 2),
+                         np.array([0.0, -0.0, np.inf, -np.inf, np.nan, 1.0, -1.0, 1 / 16, 16.0, 5805361265115136.0, 5805361265115135.0,
+                                   1e300, -1e300, 5e-324, 1.2904777690891933e-08, 0.99999999999, 15.999999])])
+    return [("exp", xe), ("log", xl), ("sin", xt), ("cos", xt), ("atan", xa)]
+
+
+def test_host_build_of_the_libm_restatements_is_the_hosts_libm():
+    """csrc/tc_glibcpow.hip.inc: tc_glibc_exp / log / sin / cos / atan (what I_exp, I_log, I_sin, I_minus_sin, I_cos,
+    I_minus_cos, I_atan and the srelu opcodes evaluate on the device, csrc/tc_pow.hip.inc) compiled for the host return the
+    bits of THIS machine's libm: every binade, every branch of glibc's routines and their boundaries, overflow / underflow /
+    subnormal results, arguments beyond 105 414 350 (the 1 800-bit reduction of branred.c), the special values"""
+    L = build_host()
+    for which, (name, x) in enumerate(_libm_arguments(3, 2_000_000)):
+        a, b = _unary(L.unary_emul_eval, which, x), _unary(L.unary_libm_eval, which, x)
+        assert np.array_equal(a, b, equal_nan=True), (name, int((~((a == b) | (np.isnan(a) & np.isnan(b)))).sum()))
+
+
+@pytest.mark.gpu
+def test_device_libm_functions_are_the_hosts_bit_for_bit():
+    import torch  # noqa: F401  (one HIP runtime per process)
+    L = build_host()
+    D = ctypes.CDLL(build_dev())
+    for which, (name, x) in enumerate(_libm_arguments(5, 4_000_000)):
+        got, want = _unary(D.crm_dev_unary, which, x), _unary(L.unary_libm_eval, which, x)
+        bad = int((~((got == want) | (np.isnan(got) & np.isnan(want)))).sum())
+        print("\ndevice %s vs this host's on %d arguments: %d mismatches" % (name, x.size, bad))
+        assert bad == 0, name
