@@ -123,14 +123,71 @@ def tape_calls_pow(tape, defines=None):
     return neg, half
 
 
+LIBM_FUNCTIONS = ("exp", "log", "sin", "cos", "atan")        # order = the harness's `which`
+
+
+def tape_calls_libm(tape):
+    """which of exp / log / sin / cos / atan a class evaluates (I_exp, I_log, I_sin, I_minus_sin, I_cos, I_minus_cos, I_atan,
+    the srelu family, I_componentwise instructions that are a plain call of one of them)"""
+    from .. import instructions as I
+    used = tape.used[1:] if hasattr(tape, "used") else np.ones(tape.n, dtype=bool)
+    by_op = {I.I_exp: {"exp"}, I.I_log: {"log"}, I.I_sin: {"sin"}, I.I_minus_sin: {"sin"}, I.I_cos: {"cos"}, I.I_minus_cos: {"cos"},
+             I.I_atan: {"atan"}, I.I_srelu: {"exp", "log"}, I.I_dsrelu: {"exp"}, I.I_ddsrelu: {"exp"}}
+    out = set()
+    for op, names in by_op.items():
+        if np.any((tape.types == op) & used):
+            out |= names
+    for i in np.flatnonzero((tape.types == I.I_componentwise) & used):
+        eq = I.componentwise_opcode(tape.pars[tape.parStart[i]:tape.parStart[i + 1]])
+        out |= by_op.get(eq, set())
+    return sorted(out)
+
+
+def libm_parity(names, n=200_000, device=None, seed=2026):
+    """the device's TC_EXP .. TC_ATAN (csrc/tc_pow.hip.inc) against live calls of this host's libm on n arguments each
+    -> {name: mismatches}"""
+    r = np.random.RandomState(seed)
+    args = {"exp": r.uniform(-700, 700, n), "log": np.exp(r.uniform(-700, 700, n)), "sin": r.uniform(-1e3, 1e3, n) * 10.0 ** r.randint(-6, 6, n),
+            "cos": r.uniform(-1e3, 1e3, n) * 10.0 ** r.randint(-6, 6, n), "atan": r.uniform(-50, 50, n) * 10.0 ** r.randint(-6, 3, n)}
+    if device is None:
+        try:
+            import torch
+            device = bool(torch.cuda.is_available())
+        except Exception:
+            device = False
+    L = build_host()
+    D = ctypes.CDLL(build_dev()) if device else None
+    dp = ctypes.POINTER(ctypes.c_double)
+    out = {}
+    for nm in names:
+        w = LIBM_FUNCTIONS.index(nm)
+        x = np.ascontiguousarray(args[nm])
+        want, got = np.empty_like(x), np.empty_like(x)
+        L.unary_libm_eval(ctypes.c_int(w), x.ctypes.data_as(dp), want.ctypes.data_as(dp), ctypes.c_long(x.size))
+        if D is not None:
+            if D.crm_dev_unary(ctypes.c_int(w), x.ctypes.data_as(dp), got.ctypes.data_as(dp), ctypes.c_long(x.size)):
+                raise RuntimeError("libm_parity: HIP error in the device harness")
+        else:
+            L.unary_emul_eval(ctypes.c_int(w), x.ctypes.data_as(dp), got.ctypes.data_as(dp), ctypes.c_long(x.size))
+        out[nm] = _same(got, want)
+    return out
+
+
 def checked_parity_class(label, tape, defines=None, check=None):
     """the parity class to PRINT: `label` (__graft_entry__.PARITY_CLASS) unless it says bit-exact, the class depends on
-    pow, and this host's pow is not the device's -> (label, check dict)"""
+    libm (pow; exp / log / sin / cos / atan), and this host's libm is not what the device restates -> (label, check dict)"""
     if label != "bit-exact":
         return label, None
     neg, half = tape_calls_pow(tape, defines)
-    if not (neg or half):
+    fns = tape_calls_libm(tape)
+    if not (neg or half or fns):
         return label, None
-    check = check if check is not None else pow_parity()
-    bad = (neg and (check["neg_half"] or check["neg_three_halves"])) or (half and check["half"])
+    bad = False
+    if neg or half:
+        check = check if check is not None else pow_parity()
+        bad = bool((neg and (check["neg_half"] or check["neg_three_halves"])) or (half and check["half"]))
+    if fns:
+        lm = libm_parity(fns)
+        check = dict(check or {}, libm=lm)
+        bad = bad or any(lm.values())
     return (DOWNGRADED if bad else label), check

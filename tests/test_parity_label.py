@@ -59,6 +59,26 @@ def test_a_faked_mismatch_downgrades_the_label(monkeypatch):
     assert powcheck.checked_parity_class("bit-exact", quad.tape, quad.defines, check=only_neg)[0] == powcheck.DOWNGRADED
 
 
+def test_classes_that_call_exp_log_sin_cos_atan_are_checked_too(monkeypatch):
+    """round 6: the other libm functions of the ISA are restated for the device as well; a class that evaluates them keeps the
+    label only if the (host build of the) restatement returns this host's bits, and a faked mismatch downgrades it"""
+    from tenscalc_amd.problems.small import opcode_zoo
+    tc.clear()
+    zoo = opcode_zoo(folder="/tmp/lbl_zoo")
+    free, box, quad = _specs()
+    assert powcheck.tape_calls_libm(zoo.tape) == ["atan", "cos", "exp", "log", "sin"]
+    assert powcheck.tape_calls_libm(box.tape) == [] and powcheck.tape_calls_libm(quad.tape) == []
+    lm = powcheck.libm_parity(powcheck.LIBM_FUNCTIONS, n=50_000, device=False)
+    assert lm == {k: 0 for k in powcheck.LIBM_FUNCTIONS}
+    good = powcheck.pow_parity(n=20_000, device=False)
+    monkeypatch.setattr(powcheck, "libm_parity", lambda names, **kw: {k: 0 for k in names})
+    label, chk = powcheck.checked_parity_class("bit-exact", zoo.tape, zoo.defines, check=good)
+    assert label == "bit-exact" and set(chk["libm"]) == set(powcheck.LIBM_FUNCTIONS)
+    monkeypatch.setattr(powcheck, "libm_parity", lambda names, **kw: {k: (3 if k == "cos" else 0) for k in names})
+    assert powcheck.checked_parity_class("bit-exact", zoo.tape, zoo.defines, check=good)[0] == powcheck.DOWNGRADED
+    assert powcheck.checked_parity_class("bit-exact", box.tape, box.defines, check=good)[0] == "bit-exact"      # calls none of them
+
+
 def test_bench_line_carries_the_check():
     """the stand-in rehearsal of bench.py (no GPU) prints the checked label and the outcome of the check"""
     env = dict(os.environ, TC_BENCH_STANDIN="1")
