@@ -693,7 +693,7 @@ CONFIGS = {
     # configs[4] is stated as batch=4096 over 8 GPUs: the largest single-GPU configuration is the whole 4096 on one GPU
     # (16 instances per CU queued behind each other: the workgroup dispatcher hands a finished instance's CU to the next
     # one, so the 367-iteration straggler no longer IS the batch time); `--batch 512` = one GPU's share of the 8-GPU run
-    "quadcopter": ("tenscalc_amd.problems.mpc_quadcopter", "mpc_quadcopter", "quadcopter_data", 4096, "ldsc4", 512,
+    "quadcopter": ("tenscalc_amd.problems.mpc_quadcopter", "mpc_quadcopter", "quadcopter_data", 4096, "ldsc4w", 512,
                    "mpc_quadcopter T=100 (1406x1406 KKT, 67 k instructions), batch=%d per GPU, fp64 (BASELINE.json "
                    "configs[4]: batch=4096; 512 = the per-GPU share over 8 GPUs)"),
 }

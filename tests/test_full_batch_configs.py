@@ -105,7 +105,7 @@ def test_quadcopter_full_batch_properties(B):
     different positions of the dispatch order."""
     import torch
     from dense_ipm import quadcopter_model
-    spec, ds, st, it, out = _run("quadcopter", "ldsc4", B, seed0=0)
+    spec, ds, st, it, out = _run("quadcopter", "ldsc4w", B, seed0=0)       # bench.py's default for this config
     assert (st == 0).all() and it.max() <= 1000
     _replicas_equal(st, it, out, B)
     for k in (0, 41, 255):

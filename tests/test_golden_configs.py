@@ -71,7 +71,7 @@ def test_oracle_reproduces_sls_trace(sls_spec, tape_oracle):
 @pytest.mark.gpu
 @pytest.mark.parametrize("which,tags", [("dcmotor", ["dcmotor_strict", "dcmotor_w32x", "dcmotor_interp", "dcmotor_ldsm4", "dcmotor_ldsc", "dcmotor_ldsc4"]),
                                         ("l1l2", ["l1l2_interp", "l1l2_ldsm4", "l1l2_ldsc4"]),
-                                        ("quadcopter", ["quadcopter_ldsm4", "quadcopter_ldsm8", "quadcopter_ldsc4", "quadcopter_interp"])])
+                                        ("quadcopter", ["quadcopter_ldsm4", "quadcopter_ldsm8", "quadcopter_ldsc4", "quadcopter_ldsc4w", "quadcopter_interp"])])
 def test_gpu_reproduces_golden(which, tags):
     import __graft_entry__ as g_
     from tenscalc_amd.runtime import HipSolver

@@ -161,7 +161,7 @@ def test_quadcopter_T100_ldsm_vs_interp_vs_oracle(libs, tmp_path):
     save_tape(spec.tape, tape)
     c = spec.classname
     res = {}
-    for tag in ("quadcopter_ldsm4", "quadcopter_ldsm8", "quadcopter_ldsc4", "quadcopter_interp"):
+    for tag in ("quadcopter_ldsm4", "quadcopter_ldsm8", "quadcopter_ldsc4", "quadcopter_ldsc4w", "quadcopter_interp"):
         obj = _load(libs[tag], B)
         for n in names:
             obj.set(n, stacked[n])
@@ -178,6 +178,9 @@ def test_quadcopter_T100_ldsm_vs_interp_vs_oracle(libs, tmp_path):
     ac = res["quadcopter_ldsc4"]          # the compiled record walk: the same stream, printed instead of interpreted
     print("ldsc4 %.0f ms" % (ac[3] * 1e3))
     assert np.array_equal(ac[0], b[0]) and np.array_equal(ac[1], b[1]) and np.array_equal(ac[2], b[2], equal_nan=True)
+    aw = res["quadcopter_ldsc4w"]         # ... with the wider staging area (bench.py's default): other steps, the same values
+    print("ldsc4w %.0f ms" % (aw[3] * 1e3))
+    assert np.array_equal(aw[0], b[0]) and np.array_equal(aw[1], b[1]) and np.array_equal(aw[2], b[2], equal_nan=True)
     print("\nquadcopter T=100, B=64: ldsm4 %.0f ms, ldsm8 %.0f ms, interp %.0f ms; iterations %d..%d"
           % (a[3] * 1e3, a8[3] * 1e3, b[3] * 1e3, a[1].min(), a[1].max()))
     assert np.array_equal(a[0], b[0]) and np.array_equal(a[1], b[1]) and np.array_equal(a[2], b[2], equal_nan=True)
