@@ -512,6 +512,7 @@ def assign_slots(T, defines, lds_slots=20000, stage=STAGE, pack_locals=None):
         pack_locals = os.environ.get("TC_LDSM_PACK_LOCALS", "1") != "0"
     local_slot = {}
     sizes = [0]
+    local_sizes = {}                             # diagnostics: packed group-local slots per group
     if pack_locals:
         slvl, _ = stream_levels(T, True)
         for g, lo in locals_.items():
@@ -556,6 +557,7 @@ def assign_slots(T, defines, lds_slots=20000, stage=STAGE, pack_locals=None):
                 local_slot[i] = q
                 heapq.heappush(busy, (last[i], q))
             sizes.append(nxt)
+            local_sizes[g] = nxt
         nLocal = max(sizes)
     else:
         nLocal = max([len(v) for v in locals_.values()], default=0)
@@ -632,7 +634,8 @@ def assign_slots(T, defines, lds_slots=20000, stage=STAGE, pack_locals=None):
     for i, q in gslot.items():
         where[i] = nLds + q
     return dict(addr=where, nLds=nLds, nGlob=nExt + nCold, nExt=nExt, consts=consts, inputs=inputs, dummy=dummy,
-                zero=zero, negzero=negzero, posinf=posinf, neginf=neginf, one=one, stage_base=stage_base, nStage=int(stage), nLocal=nLocal, nHot=nHot, nCold=nCold, hot_blocks=len(hot), cold_blocks=len(cold),
+                zero=zero, negzero=negzero, posinf=posinf, neginf=neginf, one=one, stage_base=stage_base, nStage=int(stage), nLocal=nLocal,
+                local_sizes=local_sizes, nHot=nHot, nCold=nCold, hot_blocks=len(hot), cold_blocks=len(cold),
                 lowering=L, levels=lvl, nlev=nlev)
 
 
@@ -777,6 +780,7 @@ def build_stream(T, addr, nLds, W=1, stage_base=None, nStage=0, hoist=True, pads
     lvl, nlev = stream_levels(T, nested)
     words, headers = [], []
     granges, gstats = {}, {}
+    two_step = {}
 
     def up8(n_):
         return -(-n_ // 8) * 8
@@ -985,12 +989,16 @@ def build_stream(T, addr, nLds, W=1, stage_base=None, nStage=0, hoist=True, pads
                 long_[key] = sorted(items, key=lambda it: -len(it[1]))      # similar lengths share a record
             staged.sort(key=lambda s_: -len(s_["terms"]))
             hoist = bool(staged) and idx > 0 and half >= 64 and not any(s_.get("split") for s_ in staged)
+            why = None if hoist or not staged else ("first level" if idx == 0 else "split row" if any(s_.get("split") for s_ in staged)
+                                                    else "no staging halves")
             for s_ in staged:
                 nl = sum(s_["late"])
                 if nl and not (s_["top"] == "prod" and s_["tn"] == 2 and nl <= NLATE):
-                    hoist = False
+                    hoist, why = False, why or ("more than %d late terms" % NLATE if nl > NLATE else "late term that is not a product")
             if sum(rowlen(s_) for s_ in staged) > half:            # (late terms keep their slot in the row)
-                hoist = False
+                hoist, why = False, why or "rows exceed a staging half"
+            if why:                       # diagnostics: why a level with staged rows takes two steps (class_stream()["two_step_levels"])
+                two_step[why] = two_step.get(why, 0) + 1
             info.append(dict(short=short, long_=long_, staged=staged, hoist=hoist))
 
         def late_last(s_):
@@ -1138,7 +1146,7 @@ def build_stream(T, addr, nLds, W=1, stage_base=None, nStage=0, hoist=True, pads
             rg.append((h0, len(headers) // 8))
         granges[g] = rg
         gstats[g] = (len(members), len(levels))
-    return dict(words=words, headers=headers, granges=granges, gstats=gstats)
+    return dict(words=words, headers=headers, granges=granges, gstats=gstats, two_step_levels=two_step)
 
 
 def copy_records(words, headers, pairs, nLds, W=1):
@@ -1193,7 +1201,7 @@ def class_stream(T, classname, defines, W=1, lds_slots=20000, hoist=True, nested
     unwalked = {rid[g] for g in getattr(sl["lowering"], "dead_groups", ()) if g in rid}
     validate(words, headers, table, W, nLds, nLds + sl["nGlob"], dummy=sl["dummy"], unwalked=unwalked)
     return dict(sl, words=words, headers=headers, rid=rid, table=table, out_off=out_off, nOut=len(out_addr),
-                gstats=st["gstats"], W=W)
+                gstats=st["gstats"], W=W, two_step_levels=st["two_step_levels"])
 
 
 def record_accesses(words, hdr):
