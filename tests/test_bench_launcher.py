@@ -88,3 +88,28 @@ def test_config_single_rank_standin(native_built):
     assert r.returncode == 0, r.stderr[-3000:]
     d = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
     assert d["standin"] is True and d["n_gpus"] == 1 and d["config"]["batch_total"] == 8 and "gathered" not in d
+
+
+def test_iteration_spread_and_traffic_provenance():
+    """the fields that make a batch's tail readable (bench.py: iteration_spread) and say where replayed counters come from
+    (traffic_from): floors from a measured per-iteration time, residents per CU, lockstep waste of a tile back-end"""
+    import numpy as np
+    sys.path.insert(0, ROOT)
+    import bench
+    rs = np.random.RandomState(0)
+    it = np.r_[rs.poisson(28, 4095), 765]
+    s = bench.iteration_spread(it, "ldsc4w", 4096, 0.400, (0.050, 180, 256, 1))
+    t_iter = 0.050 / 180
+    assert abs(s["ms_per_iteration_one_instance"] - t_iter * 1e3) < 1e-12 and s["residents_per_cu"] == 1
+    assert abs(s["straggler_floor_ms"] - 765 * t_iter * 1e3) < 1e-9
+    assert abs(s["throughput_floor_ms"] - it.sum() * t_iter * 1e3 / 256) < 1e-9
+    assert s["straggler_position"] == 1.0 and abs(s["batch_over_floor"] - 400.0 / s["straggler_floor_ms"]) < 1e-9
+    assert sum(s["iter_hist"]["counts"]) == it.size and s["iter_total"] == int(it.sum())
+    s4 = bench.iteration_spread(it, "ldscs", 4096, 0.400, (0.050, 180, 256, 4))
+    assert abs(s4["throughput_floor_ms"] * 4 - s["throughput_floor_ms"]) < 1e-9           # four workgroups per CU
+    assert "straggler_floor_ms" not in bench.iteration_spread(it, "ldsc4w", 4096, 0.400, None)      # --no-calib: no floors claimed
+    tile = bench.iteration_spread(rs.poisson(29, 16384), "interp8", 16384, 0.130, None)
+    assert 0 < tile["lockstep_waste"] < 0.5 and tile["tile_iter_max_mean"] > tile["iter_mean"]
+    tf = bench.traffic_from("w8x", 65536)
+    assert tf["file"] == "profiles/traffic.json" and tf["entry"] == "w8x_B65536" and "NOT a measurement of this run" in tf["how"]
+    assert bench.traffic_from("no_such_variant", 1) is None and bench.measured_traffic("no_such_variant", 1) is None
