@@ -816,8 +816,20 @@ def build_stream(T, addr, nLds, W=1, stage_base=None, nStage=0, hoist=True, pads
             sz = _staged_size(fop, tn, nt, split) + SKEW
             if sz <= nStage:
                 longest = max(longest, sz)
-    half = (max(0, nStage - longest) // 2) // 8 * 8 if hoist else 0
-    cbase, cstage = (stage_base or 0) + 2 * half, nStage - 2 * half
+    # TC_LDSM_PREFIX=k (0 = off): a hoisted dot whose first >= k terms were complete THREE levels up has those terms staged two
+    # steps ahead and folded one step ahead (an ordinary F_SUM fold, by another lane, usually on another wavefront) into the
+    # FIRST slot of its row: the fold on the level's critical path then adds up 1 + the remaining terms -- (-0.0) + partial sum
+    # is the partial sum, so the chain is the reference's.  The area behind the classic region is then four buffers (rows and
+    # prefix rows, two alternating each) instead of two.
+    PREFIX_MIN = int(os.environ.get("TC_LDSM_PREFIX", "0")) if hoist else 0
+    if PREFIX_MIN:
+        half = (max(0, nStage - longest) // 4) // 8 * 8
+        phalf = half
+    else:
+        half = (max(0, nStage - longest) // 2) // 8 * 8 if hoist else 0
+        phalf = 0
+    pbase = (stage_base or 0) + 2 * half
+    cbase, cstage = pbase + 2 * phalf, nStage - 2 * half - 2 * phalf
     for g, members in enumerate(T.groups, 1):
         levels = {}
         for i in members.tolist():
@@ -948,7 +960,7 @@ def build_stream(T, addr, nLds, W=1, stage_base=None, nStage=0, hoist=True, pads
                 skip = _DOT_SKIP.get(op, 0)
                 nterm = (len(a) - skip) // tn
                 if nStage and tn <= NSHORT and _staged_size(fop, aux, nterm, split) + SKEW <= cstage and (len(a) - skip) % tn == 0:
-                    tl, late = [], []
+                    tl, late, oldt = [], [], []
                     for q in range(nterm):
                         ids = list(ops[skip + q * tn:skip + (q + 1) * tn])
                         tw = list(a[skip + q * tn:skip + (q + 1) * tn])
@@ -970,9 +982,10 @@ def build_stream(T, addr, nLds, W=1, stage_base=None, nStage=0, hoist=True, pads
                                     raise AssertionError("nested product: operand without storage")
                         tl.append(tw)
                         late.append(prev is not None and any(T.group[j] == g and T.used[j] and lvl[j] >= prev for j in ids))
+                        oldt.append(idx >= 2 and not any(T.group[j] == g and T.used[j] and lvl[j] >= Ls[idx - 2] for j in ids))
                         if any(T.group[j] == g and T.used[j] and lvl[j] >= l_ for j in ids):
                             raise AssertionError(f"instruction {i}: a term needs a value of its own level")
-                    s_ = dict(op=op, fop=fop, aux=aux, d=d, heads=a[:skip], top=top, tn=tn, terms=tl, late=late)
+                    s_ = dict(op=op, fop=fop, aux=aux, d=d, heads=a[:skip], top=top, tn=tn, terms=tl, late=late, old=oldt)
                     # A long minimum / maximum does not depend on the order of its operands except through NaNs and
                     # the signs of zeros, and a long sum of products is DEFINED by the reference as a sum of
                     # statements of <= MAX_TERMS_PERLINE factors (instructionsTableUTHash.c:1003-1012): the chunks
@@ -995,8 +1008,30 @@ def build_stream(T, addr, nLds, W=1, stage_base=None, nStage=0, hoist=True, pads
                 nl = sum(s_["late"])
                 if nl and not (s_["top"] == "prod" and s_["tn"] == 2 and nl <= NLATE):
                     hoist, why = False, why or ("more than %d late terms" % NLATE if nl > NLATE else "late term that is not a product")
+            if hoist and PREFIX_MIN and idx >= 2:
+                # prefixes, longest first, while the prefix rows fit their buffer
+                cand = []
+                for s_ in staged:
+                    if s_["top"] == "prod" and s_["tn"] == 2 and s_["fop"] in _DOT_SKIP and not s_.get("split"):
+                        pf = 0
+                        while pf < len(s_["terms"]) and s_["old"][pf] and not s_["late"][pf]:
+                            pf += 1
+                        if pf >= PREFIX_MIN:
+                            cand.append((pf, s_))
+                used_p = 0
+                for pf, s_ in sorted(cand, key=lambda c_: -c_[0]):
+                    if used_p + up8(pf) + SKEW <= phalf:
+                        used_p += up8(pf) + SKEW
+                        s_["pfx_terms"] = s_["terms"][:pf]
+                        s_["terms"] = [None] + s_["terms"][pf:]          # None: the slot the prefix fold writes
+                        s_["late"] = [False] + s_["late"][pf:]
             if sum(rowlen(s_) for s_ in staged) > half:            # (late terms keep their slot in the row)
                 hoist, why = False, why or "rows exceed a staging half"
+            if not hoist:
+                for s_ in staged:                                   # (a level that takes two steps after all: rows as they were)
+                    if "pfx_terms" in s_:
+                        s_["terms"] = s_.pop("pfx_terms") + s_["terms"][1:]
+                        s_["late"] = [False] * (len(s_["terms"]) - len(s_["late"]) + 1) + s_["late"][1:]
             if why:                       # diagnostics: why a level with staged rows takes two steps (class_stream()["two_step_levels"])
                 two_step[why] = two_step.get(why, 0) + 1
             info.append(dict(short=short, long_=long_, staged=staged, hoist=hoist))
@@ -1053,11 +1088,12 @@ def build_stream(T, addr, nLds, W=1, stage_base=None, nStage=0, hoist=True, pads
                 n_ -= sum(s_["late"])       # the late slots are never written: the identity from the first of them on
             like = None
             if one is not None and s_["top"] == "prod" and s_["tn"] == 2 and not s_.get("split"):
-                plain = [tw for q, tw in enumerate(s_["terms"]) if len(tw) == 2 and not (hoisted and s_["late"][q])]
+                plain = [tw for q, tw in enumerate(s_["terms"]) if tw is not None and len(tw) == 2 and not (hoisted and s_["late"][q])]
                 if plain:                    # the row has plain products staged in this very step
                     like = term_key(s_, plain[0])
             pad_row(terms, s_["fop"], base, n_, like)
         toggle = 0               # which staging half the next hoisted level's early terms go to
+        ptoggle = 0              # ... and which prefix buffer the level after that one's prefix rows go to
         for idx, lv in enumerate(info):
             recs = cut(merge_short_dots(lv["short"]), K_SHORT, lambda nn, it: nn + 6) + cut(lv["long_"], K_LONG, lambda nn, it: len(it[1]) + 8)
             nxt = info[idx + 1] if idx + 1 < len(info) else None
@@ -1066,16 +1102,36 @@ def build_stream(T, addr, nLds, W=1, stage_base=None, nStage=0, hoist=True, pads
                 terms, used = {}, 0
                 hb = stage_base + toggle * half
                 toggle ^= 1
+                pfolds = {}
                 for s_ in nxt["staged"]:
                     s_["base"] = hb + used
                     for q, tw in enumerate(s_["terms"]):
-                        if not s_["late"][q]:
+                        if tw is not None and not s_["late"][q]:
                             terms.setdefault(term_key(s_, tw), []).append((s_["base"] + q, tw))
+                    if "pfx_terms" in s_:          # its prefix row was staged a step ago: folded now, into the row's first slot
+                        pfolds.setdefault((F_SUM, 0, 0), []).append((s_["base"], [len(s_["pfx_terms"]), 2, 2, s_["pbase"]]))
                     add_pads(terms, s_, s_["base"], True)
                     used += rowlen(s_)             # the late terms keep their slot in the row: the folding lane fills it
                 if used > half:
                     raise AssertionError("staging half overflow")
-                ahead_next = cut(merge_products(terms), K_SHORT, lambda nn, it: nn + 6)
+                for key, items in pfolds.items():
+                    pfolds[key] = sorted(items, key=lambda it: -it[1][0])
+                ahead_next = cut(merge_products(terms), K_SHORT, lambda nn, it: nn + 6) + cut(pfolds, K_FOLD, FOLD_COST)
+            nxt2 = info[idx + 2] if idx + 2 < len(info) else None
+            if nxt2 is not None and nxt2["hoist"] and any("pfx_terms" in s_ for s_ in nxt2["staged"]):
+                terms, used = {}, 0
+                pb = pbase + ptoggle * phalf
+                ptoggle ^= 1
+                for s_ in nxt2["staged"]:
+                    if "pfx_terms" in s_:
+                        s_["pbase"] = pb + used
+                        for q, tw in enumerate(s_["pfx_terms"]):
+                            terms.setdefault(term_key(s_, tw), []).append((s_["pbase"] + q, tw))
+                        pad_row(terms, F_SUM, s_["pbase"], len(s_["pfx_terms"]), term_key(s_, s_["pfx_terms"][0]))
+                        used += up8(len(s_["pfx_terms"])) + SKEW
+                if used > phalf:
+                    raise AssertionError("prefix buffer overflow")
+                ahead_next = ahead_next + cut(merge_products(terms), K_SHORT, lambda nn, it: nn + 6)
             staged = lv["staged"]
             if lv["hoist"]:
                 folds = {}

@@ -532,3 +532,22 @@ def test_ldsm_stream_dcmotor_as_benchmarked(native_built, tape_oracle, tmp_path)
     folds = hd[(hd[:, 0] >> 8) == lsch.K_FOLD]
     sp = folds[(folds[:, 0] & 255) == I.I_sumprod]
     assert len(sp) and sp[:, 1].max() <= 56 and cs["nCold"] == 0     # no sum of products longer than a statement line; state in LDS
+
+
+def test_ldsm_stream_prefix_folds_option(native_built, tape_oracle, tmp_path, monkeypatch):
+    """TC_LDSM_PREFIX=k (an option of the stream builder, off by default: measured slower, DESIGN 3.9 "round 6" h): the leading
+    terms of a hoisted dot that were complete three levels up are staged two steps ahead and folded one step ahead into the
+    first slot of the row -- the stream holds F_SUM folds whose destination is a staging slot, validate() finds no race among
+    the four staging buffers, and the model of the walk still reproduces every get of the oracle"""
+    from tenscalc_amd.problems.mpc_quadcopter import SOLVE_ARGS, mpc_quadcopter, quadcopter_data
+    monkeypatch.setenv("TC_LDSM_PREFIX", "4")
+    spec = mpc_quadcopter(T=20, classname="tmp_quadcopter20", folder=str(tmp_path))
+    cs = _check(spec, quadcopter_data(4, T=20), tape_oracle, SOLVE_ARGS, W=4, fuse="loop", stream_kw=dict(stage=4096))
+    hd = np.asarray(cs["headers"]).reshape(-1, 8)
+    sums = hd[((hd[:, 0] >> 8) == lsch.K_FOLD) & ((hd[:, 0] & 255) == lsch.F_SUM)]
+    lo, hi = cs["stage_base"], cs["stage_base"] + cs["nStage"]
+    into_stage = 0
+    for h in sums:
+        dst = lsch.record_body(cs["words"], h)[0][:int(h[3])]
+        into_stage += int(((dst >= lo) & (dst < hi)).sum())
+    assert into_stage > 20, "no prefix fold writes into a staging row"
