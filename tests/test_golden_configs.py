@@ -1,6 +1,14 @@
 """The committed golden vectors of BASELINE configs[2..4] and the per-iteration sls trace (tests/golden/*.npz,
 generated through the REFERENCE's own Newton loop by tests/golden/make_golden_configs.py).
 
+What these fixtures are -- and are not.  They are outputs of THIS repo's tape, walked by the oracle's interpreter under the
+reference's Newton loop: they move whenever the tape does (the elimination order of a class changed in rounds 3 and 5 and they
+were regenerated), so they catch drift between the HIP back-ends and the oracle, NOT a regression of the front-end that builds
+the tape.  What guards the front-end is independent of any tape: the dense interior-point twins of tests/dense_ipm.py
+(tests/test_tape_vs_dense_ipm.py, test_random_qp_vs_dense_ipm.py: same iterates to 1e-7 .. 1e-10, with the number of seeds
+allowed to leave the dense path written in the test), the reference's flop table (tests/test_reference_flops_table.py) and the
+reference's own emitter printing this repo's tapes (tests/test_reference_emitter_replay.py).
+
 CPU part: the oracle (restated loop) reproduces every fixture bit for bit -- the fixtures and the checker agree.
 GPU part: the HIP back-ends, called through the C-ABI, reproduce them -- bit for bit for mpc_dcmotor, l1l2 and the
 sls trace, and since round 4 for mpc_quadcopter too (its pow calls are evaluated as the host libm does, csrc/tc_glibcpow.hip.inc)."""
