@@ -2141,7 +2141,7 @@ def build_class(spec, fp_contract="fast", arch="gfx950", opt="-O3", block=64, fo
     kq.update(repr((cls, sorted(spec.defines.items()), [(n, tuple(sz)) for n, sz in spec.outputs], fp_contract, arch, opt, block,
                     stats, tag, tuple(extra_flags), roll, min_waves, lanes, recip, fast_div, inline_max, reg_budget, scratch,
                     body, waves, fuse, static_clean, forward, rcache, lds_state, share, branch_free_tails, exact, stg_blocks,
-                    lds_slots, ilp, fw_window, sched_every, tuple(tuple(a) if isinstance(a, (tuple, list)) else a for a in try_flags), refresh_outputs, compiled, lds_stage, lds_split_min, os.environ.get("TC_LDS_PAD_SLOTS", ""), os.environ.get("TC_STG_BATCH", ""), os.environ.get("TC_LDSM_FUSE", ""), os.environ.get("TC_INTERP_FUSE", ""), os.environ.get("TC_INTERP_PAIRS", ""), os.environ.get("TC_FINE_LIVES", ""), os.environ.get("TC_INTERP_WIDE_MIN", ""), os.environ.get("TC_INTERP_L4_MIN", ""), os.environ.get("TC_LDSM_LOOP_MERGE", ""), os.environ.get("TC_LDSC_DEPTH", ""), os.environ.get("TC_LDSM_PACK_LOCALS", ""), os.environ.get("TC_LDSM_ROW_SKEW", ""), os.environ.get("TC_LDSM_LATE_LAST", ""), os.environ.get("TC_LDSM_PAD_PRODUCTS", ""), os.environ.get("TC_LDSM_MERGE_PRODUCTS", ""), os.environ.get("TC_LDSM_COLD_RANK", ""), os.environ.get("TC_LDSC_TWO_PHASE", ""), os.environ.get("TC_LDSC_SPLIT_HBM", ""), os.environ.get("TC_LDSC_SCHEDB", ""), os.environ.get("TC_LDSC_BYTES", ""), os.environ.get("TC_LDSC_WPE", ""), os.environ.get("TC_LDSM_STAGE", ""), os.environ.get("TC_LDSC_CHUNK", ""), os.environ.get("TC_WPE", ""), os.environ.get("TC_LDSM_SPLIT_MIN", ""), os.environ.get("TC_LDSM_SPLIT_DIV", ""), os.environ.get("TC_LDSM_SPLIT_DIV_MIN", ""), os.environ.get("TC_LDSM_DIV_NEST", ""), os.environ.get("TC_LDSM_PREFIX", ""),
+                    lds_slots, ilp, fw_window, sched_every, tuple(tuple(a) if isinstance(a, (tuple, list)) else a for a in try_flags), refresh_outputs, compiled, lds_stage, lds_split_min, os.environ.get("TC_LDS_PAD_SLOTS", ""), os.environ.get("TC_STG_BATCH", ""), os.environ.get("TC_LDSM_FUSE", ""), os.environ.get("TC_INTERP_FUSE", ""), os.environ.get("TC_INTERP_PAIRS", ""), os.environ.get("TC_FINE_LIVES", ""), os.environ.get("TC_INTERP_WIDE_MIN", ""), os.environ.get("TC_INTERP_L4_MIN", ""), os.environ.get("TC_LDSM_LOOP_MERGE", ""), os.environ.get("TC_LDSC_DEPTH", ""), os.environ.get("TC_LDSM_PACK_LOCALS", ""), os.environ.get("TC_LDSM_ROW_SKEW", ""), os.environ.get("TC_LDSM_LATE_LAST", ""), os.environ.get("TC_LDSM_PAD_PRODUCTS", ""), os.environ.get("TC_LDSM_MERGE_PRODUCTS", ""), os.environ.get("TC_LDSM_COLD_RANK", ""), os.environ.get("TC_LDSC_TWO_PHASE", ""), os.environ.get("TC_LDSC_SPLIT_HBM", ""), os.environ.get("TC_LDSC_SCHEDB", ""), os.environ.get("TC_LDSC_BYTES", ""), os.environ.get("TC_LDSC_WPE", ""), os.environ.get("TC_LDSM_STAGE", ""), os.environ.get("TC_LDSC_CHUNK", ""), os.environ.get("TC_WPE", ""), os.environ.get("TC_LDSM_SPLIT_MIN", ""), os.environ.get("TC_LDSM_SPLIT_DIV", ""), os.environ.get("TC_LDSM_SPLIT_DIV_MIN", ""), os.environ.get("TC_LDSM_DIV_NEST", ""), os.environ.get("TC_LDSM_PREFIX", ""), os.environ.get("TC_LDSM_MERGE_FOLDS", ""),
                     os.environ.get("TC_SWEEP_UNROLL", ""))).encode())
     for f_ in sorted(os.listdir(HERE)):
         if f_.endswith(".py"):

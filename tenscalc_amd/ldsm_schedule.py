@@ -804,6 +804,7 @@ def build_stream(T, addr, nLds, W=1, stage_base=None, nStage=0, hoist=True, pads
     LATE_LAST_ON = os.environ.get("TC_LDSM_LATE_LAST", "1") != "0"
     PADS_AS_PRODUCTS = os.environ.get("TC_LDSM_PAD_PRODUCTS", "1") != "0"
     MERGE_PRODUCTS = os.environ.get("TC_LDSM_MERGE_PRODUCTS", "1") != "0"
+    MERGE_FOLDS = os.environ.get("TC_LDSM_MERGE_FOLDS", "0") == "1"
     # staging area = two alternating halves for terms computed one step ahead + the classic region, which must hold
     # the longest staged instruction of the class
     longest = 0
@@ -901,6 +902,23 @@ def build_stream(T, addr, nLds, W=1, stage_base=None, nStage=0, hoist=True, pads
                         items.append((d, list(a) + [pads[0] * 2, one * 2] * ((nmax_ - k_[1]) // 2)))
                 short[(op, nmax_, 0)] = items
             return short
+
+        def merge_fold_dots(folds):
+            """hoisted folds -(acc) join the record of the folds h0 - (acc) of the same step when that saves a record, as
+            (-0.0) - (acc): the same value for every acc that is a number (signed zeros included); for a NaN the sign
+            bit of the NaN differs, which no instruction of the ISA reads (the host and the device differ in the sign of
+            the NaNs they generate anyway).  Likewise (-(acc)) / d as ((-0.0) - (acc)) / d."""
+            if not (MERGE_FOLDS and pads is not None):
+                return folds
+            for plain, full in ((I.I_minus_dot, I.I_plus_minus_dot), (I.I_minus_dot_div, I.I_plus_minus_dot_div)):
+                for key in [k_ for k_ in folds if k_[0] == plain]:
+                    kf = (full,) + key[1:]
+                    if kf in folds and -(-(len(folds[key]) + len(folds[kf])) // LANES) < -(-len(folds[key]) // LANES) + -(-len(folds[kf]) // LANES):
+                        for d, body in folds.pop(key):
+                            body = list(body)
+                            body[1:3] = [pads[0] * 2, body[1]]
+                            folds[kf].append((d, body))
+            return folds
 
         def cut(groups_, kind, cost):
             recs = []
@@ -1138,6 +1156,7 @@ def build_stream(T, addr, nLds, W=1, stage_base=None, nStage=0, hoist=True, pads
                 for s_ in staged:
                     folds.setdefault((s_["fop"], 0, s_["aux"] | (LATE_LAST if late_last(s_) else 0) | (dn_bits(s_) << DN_SHIFT)),
                                      []).append(fold_item(s_, s_["base"], True))
+                folds = merge_fold_dots(folds)
                 for key, items in folds.items():
                     folds[key] = sorted(items, key=lambda it: -it[1][0])
                 emit(recs + cut(folds, K_FOLD, FOLD_COST) + ahead_next)

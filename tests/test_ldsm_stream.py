@@ -551,3 +551,23 @@ def test_ldsm_stream_prefix_folds_option(native_built, tape_oracle, tmp_path, mo
         dst = lsch.record_body(cs["words"], h)[0][:int(h[3])]
         into_stage += int(((dst >= lo) & (dst < hi)).sum())
     assert into_stage > 20, "no prefix fold writes into a staging row"
+
+
+def test_ldsm_stream_merged_folds_option(native_built, tape_oracle, tmp_path, monkeypatch):
+    """TC_LDSM_MERGE_FOLDS=1 (an option of the stream builder, off by default: no gain measured, DESIGN 3.9 "round 6" i): folds
+    -(acc) of a hoisted level join the record of the level's folds h0 - (acc) as (-0.0) - (acc) -- fewer fold records, no
+    I_minus_dot fold left beside an I_plus_minus_dot one in a step, and the model of the walk reproduces every get of the oracle"""
+    from tenscalc_amd import instructions as I
+    from tenscalc_amd.problems.mpc_quadcopter import SOLVE_ARGS, mpc_quadcopter, quadcopter_data
+    spec = mpc_quadcopter(T=20, classname="tmp_quadcopter20", folder=str(tmp_path))
+    T = lsch.fused_tape(spec.tape, spec.defines)
+
+    def folds(cs):
+        hd = np.asarray(cs["headers"]).reshape(-1, 8)
+        return hd[(hd[:, 0] >> 8) == lsch.K_FOLD]
+    n0 = len(folds(lsch.class_stream(T, spec.classname, spec.defines, W=4)))
+    monkeypatch.setenv("TC_LDSM_MERGE_FOLDS", "1")
+    cs = _check(spec, quadcopter_data(4, T=20), tape_oracle, SOLVE_ARGS, W=4, fuse="loop")
+    f1 = folds(cs)
+    assert len(f1) < n0
+    assert (f1[:, 0] & 255 == I.I_plus_minus_dot).any()
