@@ -30,7 +30,8 @@ so = spec.build(**kw)
 meta = os.path.splitext(so)[0] + ".levels.npz"
 if mode == "build":
     T = lsch.fused_tape(spec.tape, spec.defines)
-    cs = lsch.class_stream(T, spec.classname, spec.defines, W=int(kw["waves"]), lds_slots=kw.get("lds_slots", 20000))
+    cs = lsch.class_stream(T, spec.classname, spec.defines, W=int(kw["waves"]), lds_slots=kw.get("lds_slots", 20000),
+                           stage=int(kw.get("lds_stage", 0)), split=int(kw.get("lds_split_min", 0)) or True)
     np.savez(meta, headers=np.asarray(cs["headers"], dtype=np.int64).reshape(-1, 8), table=np.asarray(cs["table"], dtype=np.int64))
     print(so, meta)
     sys.exit(0)
