@@ -11,7 +11,7 @@
 #include <cstdlib>
 #include <vector>
 
-template <int NL, int NS, bool NT, bool SEQ, int G = 1>
+template <int NL, int NS, bool NT, bool SEQ, int G = 1, int D = 1>
 __global__ void __launch_bounds__(1024) walk(double *state, size_t rows, int iters, double *sink) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, W = blockDim.x >> 6;
   double *tile = state + (size_t)blockIdx.x * rows * 64;
@@ -24,7 +24,11 @@ __global__ void __launch_bounds__(1024) walk(double *state, size_t rows, int ite
     for (int k = 0; k < NL; k++) {
       size_t r;
       if (SEQ) { r = seq++; if (seq >= rows) seq = 0; }
-      else {
+      else if (D > 1) {      // the two rows of a pair are issued D loads apart: k = blk * 2D + member * D + j
+        const int blk = k / (2 * D), member = (k / D) & 1, j = k % D;
+        const unsigned hp = (h + 0x9e3779b9u * (unsigned)(it * 64 + blk * D + j + 1)) * 1664525u + 1013904223u;
+        r = ((size_t)(__builtin_amdgcn_readfirstlane(hp) >> 8) % (rows / 2)) * 2 + member;
+      } else {
         if (k % G == 0) h = h * 1664525u + 1013904223u;
         r = ((size_t)(__builtin_amdgcn_readfirstlane(h) >> 8) % (rows / G)) * G + k % G;
       }
@@ -48,15 +52,15 @@ __global__ void __launch_bounds__(1024) walk(double *state, size_t rows, int ite
   if (acc == 12345.678) sink[0] = acc;       // (keeps the loads alive)
 }
 
-template <int NL, int NS, bool NT, bool SEQ, int G = 1>
+template <int NL, int NS, bool NT, bool SEQ, int G = 1, int D = 1>
 static void run(const char *name, double *state, size_t rows, int tiles, int W, double *sink) {
   const int iters = 4000 / (NL + NS) * 8;
   hipEvent_t e0, e1;
   hipEventCreate(&e0); hipEventCreate(&e1);
-  walk<NL, NS, NT, SEQ, G><<<tiles, 64 * W>>>(state, rows, iters / 8, sink);
+  walk<NL, NS, NT, SEQ, G, D><<<tiles, 64 * W>>>(state, rows, iters / 8, sink);
   hipDeviceSynchronize();
   hipEventRecord(e0);
-  walk<NL, NS, NT, SEQ, G><<<tiles, 64 * W>>>(state, rows, iters, sink);
+  walk<NL, NS, NT, SEQ, G, D><<<tiles, 64 * W>>>(state, rows, iters, sink);
   hipEventRecord(e1);
   hipEventSynchronize(e1);
   float ms;
@@ -86,6 +90,11 @@ int main(int argc, char **argv) {
   run<24, 8, true, false, 2>("hashed runs of 2 rows, 24 loads + 8 stores, nt", state, rows, tiles, 8, sink);
   run<24, 8, true, false, 4>("hashed runs of 4 rows, 24 loads + 8 stores, nt", state, rows, tiles, 8, sink);
   run<24, 8, true, false, 8>("hashed runs of 8 rows, 24 loads + 8 stores, nt", state, rows, tiles, 8, sink);
+  // ... and when the two rows of a pair are not issued back to back but D loads apart (loads only)
+  run<32, 0, true, false, 2, 1>("hashed pairs, 32 loads, back to back", state, rows, tiles, 8, sink);
+  run<32, 0, true, false, 2, 2>("hashed pairs, 32 loads, 2 loads apart", state, rows, tiles, 8, sink);
+  run<32, 0, true, false, 2, 4>("hashed pairs, 32 loads, 4 loads apart", state, rows, tiles, 8, sink);
+  run<32, 0, true, false, 2, 16>("hashed pairs, 32 loads, 16 loads apart", state, rows, tiles, 8, sink);
   // the tile machine's other knob: more tiles than CUs (a batch of 32 768 / 65 536)
   run<24, 8, true, false>("hashed rows, 24 loads + 8 stores, nt", state, rows / 2, tiles * 2, 8, sink);
   hipFree(state); hipFree(sink);
