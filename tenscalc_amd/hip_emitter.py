@@ -1121,7 +1121,8 @@ def emit_class(spec, fp_contract="fast", block=64, stats=False, roll=True, min_w
     consts = []
     if interp:
         from . import interp_schedule as isch
-        consts = isch.constant_rows(T, L)[0]
+        cs_interp = isch.class_stream(T, L, cls, int(waves))     # (the rows above the computed values: constants, split reductions)
+        consts = cs_interp["consts"]
     dummy = 1 if (forward and lanes > 1 and branch_free_tails) else 0
     nmp = max(1, L.nPriv) + dummy                                  # + TC_DUMMY
     if P.exact and L.dreduce:                                      # staging area of the ordered sums (only tapes that sum
@@ -1216,7 +1217,7 @@ def emit_class(spec, fp_contract="fast", block=64, stats=False, roll=True, min_w
     stream, copy_rng, out_rng = [], {}, None
     if interp:
         from . import interp_schedule as isch
-        cs = isch.class_stream(T, L, cls, int(waves))
+        cs = cs_interp
         stream, granges, gstats = cs["dev_words"], cs["granges"], cs["gstats"]      # rows as byte offsets (device_words)
         copy_rng, out_rng, consts = cs["copy_rng"], cs["out_rng"], cs["consts"]
         arr = isch.as_array(stream + [0] * 8)          # the header prefetch looks one record past the end
@@ -1224,8 +1225,9 @@ def emit_class(spec, fp_contract="fast", block=64, stats=False, roll=True, min_w
                  "static __device__ const int tc_code[] __attribute__((aligned(64))) = {\n")
         for k0 in range(0, arr.size, 32):
             w.append(",".join(str(int(x)) for x in arr[k0:k0 + 32]) + ",\n")
+        # (the rows split reductions lead with hold +-inf: interp_schedule.split_long; the tape itself has no such constant)
         w.append("};\nstatic __device__ const double tc_consts[] = {"
-                 + ", ".join(_lit(v) for v in consts) + ("" if consts else "0.0") + "};\n"
+                 + ", ".join(("-" if v < 0 else "") + "__builtin_inf()" if v in (float("inf"), float("-inf")) else _lit(v) for v in consts) + ("" if consts else "0.0") + "};\n"
                  "static __device__ const int tc_rng[] __attribute__((aligned(64))) = {"
                  + ", ".join(str(int(x)) for x in cs["table"]) + "};\n"
                  f"#define TC_NCONST {len(consts)}\n#define TC_NPRIV {L.nPriv}\n#define TC_W {int(waves)}\n"
@@ -2141,7 +2143,7 @@ def build_class(spec, fp_contract="fast", arch="gfx950", opt="-O3", block=64, fo
     kq.update(repr((cls, sorted(spec.defines.items()), [(n, tuple(sz)) for n, sz in spec.outputs], fp_contract, arch, opt, block,
                     stats, tag, tuple(extra_flags), roll, min_waves, lanes, recip, fast_div, inline_max, reg_budget, scratch,
                     body, waves, fuse, static_clean, forward, rcache, lds_state, share, branch_free_tails, exact, stg_blocks,
-                    lds_slots, ilp, fw_window, sched_every, tuple(tuple(a) if isinstance(a, (tuple, list)) else a for a in try_flags), refresh_outputs, compiled, lds_stage, lds_split_min, os.environ.get("TC_LDS_PAD_SLOTS", ""), os.environ.get("TC_STG_BATCH", ""), os.environ.get("TC_LDSM_FUSE", ""), os.environ.get("TC_INTERP_FUSE", ""), os.environ.get("TC_INTERP_PAIRS", ""), os.environ.get("TC_FINE_LIVES", ""), os.environ.get("TC_INTERP_WIDE_MIN", ""), os.environ.get("TC_INTERP_L4_MIN", ""), os.environ.get("TC_LDSM_LOOP_MERGE", ""), os.environ.get("TC_LDSC_DEPTH", ""), os.environ.get("TC_LDSM_PACK_LOCALS", ""), os.environ.get("TC_LDSM_ROW_SKEW", ""), os.environ.get("TC_LDSM_LATE_LAST", ""), os.environ.get("TC_LDSM_PAD_PRODUCTS", ""), os.environ.get("TC_LDSM_MERGE_PRODUCTS", ""), os.environ.get("TC_LDSM_COLD_RANK", ""), os.environ.get("TC_LDSC_TWO_PHASE", ""), os.environ.get("TC_LDSC_SPLIT_HBM", ""), os.environ.get("TC_LDSC_SCHEDB", ""), os.environ.get("TC_LDSC_BYTES", ""), os.environ.get("TC_LDSC_WPE", ""), os.environ.get("TC_LDSM_STAGE", ""), os.environ.get("TC_LDSC_CHUNK", ""), os.environ.get("TC_WPE", ""), os.environ.get("TC_LDSM_SPLIT_MIN", ""), os.environ.get("TC_LDSM_SPLIT_DIV", ""), os.environ.get("TC_LDSM_SPLIT_DIV_MIN", ""), os.environ.get("TC_LDSM_DIV_NEST", ""), os.environ.get("TC_LDSM_PREFIX", ""), os.environ.get("TC_LDSM_MERGE_FOLDS", ""),
+                    lds_slots, ilp, fw_window, sched_every, tuple(tuple(a) if isinstance(a, (tuple, list)) else a for a in try_flags), refresh_outputs, compiled, lds_stage, lds_split_min, os.environ.get("TC_LDS_PAD_SLOTS", ""), os.environ.get("TC_STG_BATCH", ""), os.environ.get("TC_LDSM_FUSE", ""), os.environ.get("TC_INTERP_FUSE", ""), os.environ.get("TC_INTERP_PAIRS", ""), os.environ.get("TC_FINE_LIVES", ""), os.environ.get("TC_INTERP_WIDE_MIN", ""), os.environ.get("TC_INTERP_L4_MIN", ""), os.environ.get("TC_LDSM_LOOP_MERGE", ""), os.environ.get("TC_LDSC_DEPTH", ""), os.environ.get("TC_LDSM_PACK_LOCALS", ""), os.environ.get("TC_LDSM_ROW_SKEW", ""), os.environ.get("TC_LDSM_LATE_LAST", ""), os.environ.get("TC_LDSM_PAD_PRODUCTS", ""), os.environ.get("TC_LDSM_MERGE_PRODUCTS", ""), os.environ.get("TC_LDSM_COLD_RANK", ""), os.environ.get("TC_LDSC_TWO_PHASE", ""), os.environ.get("TC_LDSC_SPLIT_HBM", ""), os.environ.get("TC_LDSC_SCHEDB", ""), os.environ.get("TC_LDSC_BYTES", ""), os.environ.get("TC_LDSC_WPE", ""), os.environ.get("TC_LDSM_STAGE", ""), os.environ.get("TC_LDSC_CHUNK", ""), os.environ.get("TC_WPE", ""), os.environ.get("TC_LDSM_SPLIT_MIN", ""), os.environ.get("TC_LDSM_SPLIT_DIV", ""), os.environ.get("TC_LDSM_SPLIT_DIV_MIN", ""), os.environ.get("TC_LDSM_DIV_NEST", ""), os.environ.get("TC_LDSM_PREFIX", ""), os.environ.get("TC_LDSM_MERGE_FOLDS", ""), os.environ.get("TC_INTERP_SPLIT_LONG", ""),
                     os.environ.get("TC_SWEEP_UNROLL", ""))).encode())
     for f_ in sorted(os.listdir(HERE)):
         if f_.endswith(".py"):

@@ -121,6 +121,76 @@ def _spread(level_records, W, streams):
         streams[k] += [OP_BARRIER, 0, 0, 0, 0, 0, 8, 0]
 
 
+# ---- long reductions in parallel parts (round 6) ---------------------------------------------------------------------------
+# A long record is ONE wavefront fetching 32 operands, waiting a memory round trip, folding them, fetching the next 32: a
+# 1 992-operand sum of products is 63 round trips while the other wavefronts of the tile wait at the level's barrier (l1l2: ten
+# such records per Newton iteration, each alone in its level).  They are cut into parts that ordinary records of the same level
+# evaluate side by side, and one more record combines the parts in order -- with the reference's result, bit for bit:
+#   I_sumprod  the reference prints a long sum of products as statements of <= MAX_TERMS_PERLINE = 100 factors,
+#              m[r] = line1; m[r] += line2; ... (instructionsTableUTHash.c:173,1003-1012): the parts ARE those lines, the
+#              combining record is the ordered sum line1 + line2 + ...
+#   I_min / I_max / I_max_abs   `if (acc > x) acc = x` from the first operand (:1236-1313): a NaN later in the list is skipped,
+#              a NaN in front sticks, of equal values (+0 / -0) the first stays.  Part 0 is the chain over the first operands;
+#              the other parts start from a constant that never wins (+inf, -inf, 0 for absolute values), so a NaN at their
+#              head is skipped as the reference skips it; the combining record is the same chain over the parts, in order
+#   I_clp      from DBL_MAX (:1315-1331): every part is the chain over its own (x, dx) pairs from DBL_MAX, combined by I_min
+SPLIT_LONG_OPS = {I.I_sumprod, I.I_min, I.I_max, I.I_max_abs, I.I_clp}
+
+
+def split_long(op, aux, a, rows, W=8):
+    """operand words `a` of one long instruction -> ([(op, aux, operand words, dest row)] parts, (op, aux, operand words) of
+    the combining instruction), or None when the instruction is left alone.  rows: the _ExtraRows of the class."""
+    n = len(a)
+    if n < int(_knob("TC_INTERP_SPLIT_LONG", 256)) or op not in SPLIT_LONG_OPS:
+        return None
+    if op == I.I_sumprod:
+        if aux < 1 or n % aux:
+            return None
+        nterm, bounds, start, nS = n // aux, [], 0, 0
+        for t in range(nterm - 1):              # TcSumprod::step: the line is closed behind a term once 100 factors are in it
+            nS += aux
+            if nS >= 100:
+                bounds.append((start, (t + 1) * aux))
+                start, nS = (t + 1) * aux, 0
+        bounds.append((start, n))
+        if len(bounds) < 2:
+            return None
+        parts = [(I.I_sumprod, aux, a[s_:e_], rows.new_row()) for s_, e_ in bounds]
+        return parts, (I.I_sum, 0, [d * 2 for _, _, _, d in parts])
+    unit = 2 if op == I.I_clp else 1
+    P = min(W, n // (64 * unit))
+    if P < 2:
+        return None
+    lead = {I.I_min: float("inf"), I.I_max: float("-inf"), I.I_max_abs: 0.0}.get(op)
+    nl = 0 if lead is None else 1
+    m = -(-(n + nl * (P - 1)) // (P * LONG_CHUNK)) * LONG_CHUNK     # words per part, the leading constant included: whole fetch chunks
+    parts, s_ = [], 0
+    while s_ < n:
+        head = [rows.const(lead) * 2] if (s_ and nl) else []
+        e_ = s_ + m - len(head)
+        parts.append((op, aux, head + a[s_:e_], rows.new_row()))
+        s_ = e_
+    return parts, (I.I_min if op == I.I_clp else op, 0, [d * 2 for _, _, _, d in parts])
+
+
+class _ExtraRows:
+    """rows above the tape's constants: constants the split records lead with, and the rows of their parts (initialised like
+    constants by the kernel prologue, then written before they are read in every evaluation of their group)"""
+
+    def __init__(self, base):
+        self.base, self.vals, self._c = base, [], {}
+
+    def const(self, v):
+        if v not in self._c:
+            self._c[v] = self.base + len(self.vals)
+            self.vals.append(v)
+        return self._c[v]
+
+    def new_row(self):
+        self.vals.append(0.0)
+        return self.base + len(self.vals) - 1
+
+
 NA_PAIR, NB_PAIR = 6, 3   # operand counts of the producer / the consumer inside a pair record (tc_pair<NA, NB>)
 K_PAIR = 3                # K code of a pair record
 # opcodes tc_pair_vals evaluates (csrc/tc_interp.hip.inc): the shapes that make up nearly all single-reader producers
@@ -146,14 +216,15 @@ def _pair_records(key, items):
     return out
 
 
-def build_stream(T, row_of, W=1, fusable=None):
+def build_stream(T, row_of, W=1, fusable=None, extra=None):
     """Returns (words, ranges, level statistics): ranges[g] = [(start, end)] * W, the record range
     each of the W cooperating waves walks for dependency group g+1.
 
     row_of(j): state row (relative to the scratch base) holding the value of instruction j.
     fusable[j] (optional): instruction j has exactly one reader, in its own group, and no entry point reads it.  Such a
     producer is evaluated INSIDE its consumer's record (a pair record: 8 producer/consumer pairs of one shape) and never
-    stored: one store and one load of a 512-byte row less per pair.  The arithmetic of both instructions is untouched."""
+    stored: one store and one load of a 512-byte row less per pair.  The arithmetic of both instructions is untouched.
+    extra (an _ExtraRows, W > 1): long reductions are evaluated in parallel parts + one combining record (split_long)."""
     words = []
     ranges = []
     stats = []
@@ -235,13 +306,23 @@ def build_stream(T, row_of, W=1, fusable=None):
         inside = {j for j, _ in host.values()}
         streams = [[] for _ in range(W)]
         npair = 0
+        nsplit = 0
         for l_ in sorted(levels):
             shapes = {}
             pshapes = {}
+            post = {}               # combining records of this level's split reductions: a level of their own
             for i in levels[l_]:
                 if i in inside:
                     continue
                 op, aux, a, d = enc(i)
+                sp = split_long(op, aux, a, extra, W) if (extra is not None and W > 1 and i not in host) else None
+                if sp is not None:
+                    for pop, paux, pa, pd in sp[0]:
+                        shapes.setdefault((pop, len(pa), paux), []).append((pd, pa))
+                    fop, faux, fa = sp[1]
+                    post.setdefault((fop, len(fa), faux), []).append((d, fa))
+                    nsplit += 1
+                    continue
                 if i in host:
                     j, p = host[i]
                     opA, auxA, aA, _ = enc(j)
@@ -258,12 +339,17 @@ def build_stream(T, row_of, W=1, fusable=None):
                 recs += _pair_records(key, items)
             if recs:
                 _spread(recs, W, streams)
+            if post:
+                recs = []
+                for (op, n, aux), items in sorted(post.items()):
+                    recs += _records(op, n, aux, items, W)
+                _spread(recs, W, streams)
         rg = []
         for k in range(W):
             rg.append((len(words), len(words) + len(streams[k])))
             words += streams[k]
         ranges.append(rg)
-        stats.append((len(members), len(levels), npair))
+        stats.append((len(members), len(levels), npair, nsplit))
     return words, ranges, stats
 
 
@@ -493,7 +579,10 @@ def class_stream(T, L, classname, W=1):
             return int(lf.idx)
         raise AssertionError(lf.kind)
     fusable = L.single_local if os.environ.get("TC_INTERP_PAIRS", "1") != "0" else None
-    words, granges, gstats = build_stream(T, row_of, W, fusable)
+    extra = _ExtraRows(L.nPriv + len(consts)) if W > 1 else None
+    words, granges, gstats = build_stream(T, row_of, W, fusable, extra)
+    if extra is not None:
+        consts = consts + extra.vals          # (a new list: the rows above the tape's constants)
     copy_rng = {}
     for e in T.copies:
         if any(L.external[d] for d in e["dst"]):

@@ -174,8 +174,9 @@ def _check(spec, data, tape_oracle, args, W=1):
     for i in range(1, T.n + 1):            # inputs, internal sets, constants
         if T.isset[i - 1] and (L.external[i] or L.pslot[i] >= 0):
             m[base + cs["row_of"](i)] = val(i)
-    for i, r in cs["const_row"].items():
-        m[base + r] = cs["consts"][r - L.nPriv]
+    for k, v in enumerate(cs["consts"]):   # the kernel prologue: the tape's constants, then the rows of split reductions
+        m[base + L.nPriv + k] = v
+    assert all(cs["consts"][r - L.nPriv] == float(T.pars[T.parStart[i - 1]]) for i, r in cs["const_row"].items())
     needed = sorted({g for e in T.gets for g in e["parents"]})
     for g in needed:
         walk(cs["words"], cs["granges"][g - 1], m, base)
@@ -329,3 +330,62 @@ def test_shape_masks_cover_every_record_the_device_can_meet(native_built, tmp_pa
     for k, v in m.items():
         assert "#define TC_OPS_%s 0x%xULL\n" % (k, v) in src
     assert src.count("#define TC_OPS_") == len(m) + 1            # + TC_OPS_GIVEN
+
+
+@pytest.mark.parametrize("op,aux", [(I.I_min, 0), (I.I_max, 0), (I.I_max_abs, 0), (I.I_clp, 0), (I.I_sumprod, 2), (I.I_sumprod, 3)])
+def test_split_long_reductions_keep_the_reference_result(op, aux):
+    """interp_schedule.split_long: a long reduction evaluated as parallel parts + one combining instruction returns the bits
+    of the reference's chain -- also with NaNs in front / in the middle / at the head of a part, with +0 and -0 competing for
+    a minimum, with infinities, with nothing to clip (DBL_MAX), and with the I_sumprod statement split every 100 factors"""
+    rng = np.random.RandomState(5)
+
+    def bits(x):
+        return np.float64(x).view(np.int64)
+    n = 1200 if op != I.I_sumprod else 996 * aux
+    cases = []
+    for trial in range(40):
+        v = rng.standard_normal(n)
+        if op == I.I_sumprod:
+            v *= 10.0 ** rng.randint(-8, 8, n)           # sums whose order matters
+        kind = trial % 8
+        if kind == 1:
+            v[0] = np.nan
+        elif kind == 2:
+            v[rng.randint(1, n, 5)] = np.nan
+        elif kind == 3:                                   # NaN at the head of every later part, and the operands before it
+            v[np.arange(32, n, 32)] = np.nan
+            v[np.arange(31, n, 32)] = np.nan
+        elif kind == 4:
+            v[:] = np.where(rng.rand(n) < .5, 0.0, -0.0)
+        elif kind == 5:
+            v[rng.randint(0, n, 7)] = np.inf
+            v[rng.randint(0, n, 7)] = -np.inf
+        elif kind == 6 and op == I.I_clp:
+            v[1::2] = np.abs(v[1::2])                     # no dx < 0: DBL_MAX
+        elif kind == 7:
+            v[:] = np.abs(v) + 1.0 if op in (I.I_min, I.I_clp) else -np.abs(v) - 1.0
+        cases.append(v)
+    for v in cases:
+        rows = isch._ExtraRows(10 * n)
+        a = [2 * k for k in range(n)]                     # operand k lives in row k
+        sp = isch.split_long(op, aux, a, rows)
+        assert sp is not None and len(sp[0]) >= 2
+        m = {k: f64(x) for k, x in enumerate(v)}
+        for k, c in enumerate(rows.vals):
+            m[rows.base + k] = f64(c)
+        whole = _eval(op, aux, [m[x >> 1] for x in a], [0] * n)
+        for pop, paux, pa, pd in sp[0]:                   # the parts only read operands and constants: any order
+            m[pd] = _eval(pop, paux, [m[x >> 1] for x in pa], [x & 1 for x in pa])
+        fop, faux, fa = sp[1]
+        got = _eval(fop, faux, [m[x >> 1] for x in fa], [x & 1 for x in fa])
+        assert bits(got) == bits(whole) or (got != got and whole != whole), (I.NAMES[op], got, whole)
+    assert isch.split_long(op, aux, [2 * k for k in range(64)], isch._ExtraRows(1000)) is None      # short ones are left alone
+
+
+def test_stream_l1l2_splits_its_long_reductions(native_built, tape_oracle, tmp_path):
+    """the l1l2 estimation problem at a horizon whose reductions are long enough to be split: parts + combining records in the
+    stream, every instruction's value still the oracle's"""
+    from tenscalc_amd.problems.l1l2 import SOLVE_ARGS, l1l2, l1l2_data
+    spec = l1l2(N=140, classname="tmp_l1l2_140", folder=str(tmp_path))
+    cs = _check(spec, l1l2_data(3, N=140), tape_oracle, SOLVE_ARGS, W=8)
+    assert sum(s_[3] for s_ in cs["gstats"]) >= 4
