@@ -699,6 +699,17 @@ CONFIGS = {
 }
 
 
+def default_variant(config, var0, B):
+    """the back-end a config runs on when --variant is not given, by this rank's batch.  l1l2: the tile machine needs the
+    whole machine's worth of tiles -- its batch time is one tile's solve, 67-69 ms, up to 4 096 instances -- while the LDS walk
+    queues instances of 2.8 ms on 256 CUs: 2 048 / 4 096 / 8 192 per GPU: 24.1 / 47.1 / 91.9 ms `ldsc4` against 66.6 / 68.5 /
+    78.8 ms `interp8` (profiles/r06_l1l2_share.log), so one GPU's share of configs[2] over 8 GPUs (2 048) runs on `ldsc4`.
+    mpc_dcmotor and mpc_quadcopter keep their variant at every share."""
+    if config == "l1l2" and B <= 6144:
+        return "ldsc4"
+    return var0
+
+
 def bench_config(args, R):
     """python bench.py --config l1l2|dcmotor|quadcopter [--variant V] [--batch B | --total T]: one step = one batched
     solve of this rank's instances with the inputs resident in HBM; same timing contract and JSON fields as the sls line.
@@ -731,7 +742,7 @@ def bench_config(args, R):
     else:
         B = Bmax = args.batch or B0
         lo = rank * B
-    variant = args.variant or var0                       # any key of __graft_entry__.VARIANT_KW (interp8, ldsm4, strict, ...)
+    variant = args.variant or default_variant(args.config, var0, Bmax)      # any key of __graft_entry__.VARIANT_KW
     # (mpc_dcmotor: the compiled LDS walk with four instances resident per CU is the fastest bit-exact back-end at both the
     # whole sweep on one GPU -- 21.2 ms against 24.7 `strict`, 21.8 `interp4` -- and one GPU's share of it -- 3.1 ms per 4096
     # against 5.3 `w32x`: profiles/r05_dcmotor_variants.log)

@@ -113,3 +113,21 @@ def test_iteration_spread_and_traffic_provenance():
     tf = bench.traffic_from("w8x", 65536)
     assert tf["file"] == "profiles/traffic.json" and tf["entry"] == "w8x_B65536" and "NOT a measurement of this run" in tf["how"]
     assert bench.traffic_from("no_such_variant", 1) is None and bench.measured_traffic("no_such_variant", 1) is None
+
+
+def test_default_variant_by_share():
+    """--config runs without --variant pick the back-end by THIS rank's batch: one GPU's share of configs[2] over 8 GPUs (2 048
+    instances of l1l2) runs on the LDS walk, the whole 16 384 on the tile machine (profiles/r06_l1l2_share.log); the MPC configs
+    keep their variant; every variant named is one build() provides for that config"""
+    sys.path.insert(0, ROOT)
+    import bench
+    import __graft_entry__ as g
+    var0 = {k: v[4] for k, v in bench.CONFIGS.items()}
+    assert bench.default_variant("l1l2", var0["l1l2"], 16384) == "interp8"
+    assert bench.default_variant("l1l2", var0["l1l2"], 2048) == "ldsc4"
+    assert bench.default_variant("l1l2", var0["l1l2"], 8192) == "interp8"
+    for cfg in ("dcmotor", "quadcopter"):
+        assert {bench.default_variant(cfg, var0[cfg], b) for b in (512, 4096, 32768)} == {var0[cfg]}
+    src = open(os.path.join(ROOT, "__graft_entry__.py")).read()
+    for tag in ("l1l2_ldsc4", "l1l2_interp8", "dcmotor_" + var0["dcmotor"], "quadcopter_" + var0["quadcopter"]):
+        assert tag in src or tag.split("_", 1)[1] in g.VARIANT_KW
