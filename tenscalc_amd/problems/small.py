@@ -71,3 +71,20 @@ def sensitivity_ls(N=12, n=3, ns=2, classname="tmp_sens", **options):
                            constraints=[tc.tsum(x) == .1, x >= 0], outputExpressions=outs,
                            outputNames=["J", "x", "p", "Hess", "Lf_u", "Du1", "DfDu1", "D2fDu1"], parameters=[A, b],
                            lambdaUpdate="additive", **options)
+
+
+def long_reductions(M=600, N=12, n=4, classname="tmp_long_reductions", **options):
+    """long minimum / maximum / infinity norm / clp / inner product over parameters of M entries, as OUTPUT expressions of a
+    small box-constrained least-squares problem (evaluated once, by getOutputs; the solver never sees v, w): what the tile
+    machine evaluates as parallel parts + a combining record (interp_schedule.split_long) -- tests/test_gpu_opcodes.py feeds
+    them NaNs, signed zeros and infinities"""
+    A = tc.Tvariable("A", (N, n))
+    b = tc.Tvariable("b", (N,))
+    x = tc.Tvariable("x", (n,))
+    v = tc.Tvariable("v", (M,))
+    w = tc.Tvariable("w", (M,))
+    J = tc.norm2(A * x - b) / N
+    outs = [J, x, tc.tmin(v), tc.tmax(v), tc.norminf(v), tc.clp(v, w), tc.tprod(v, [-1], w, [-1])]
+    return cmex2optimizeCS(classname=classname, objective=J, optimizationVariables=[x],
+                           constraints=[x >= 0, x <= .05], outputExpressions=outs,
+                           outputNames=["J", "x", "vmin", "vmax", "vinf", "vclp", "vdotw"], parameters=[A, b, v, w], **options)

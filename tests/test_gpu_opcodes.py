@@ -86,3 +86,67 @@ def test_class_from_reference_dialect_cg_files(tmp_path, sls_spec):
                                               c + "_set_x": x0}, c + "_getOutputs", B, mu0=SOLVE_ARGS["mu0"],
                                              maxIter=SOLVE_ARGS["maxIter"])
     assert np.array_equal(st, rst) and np.array_equal(it, rit) and np.array_equal(got, ref)
+
+
+def _adversarial(B, M, rs):
+    """operand lists for long reductions: ordinary values, NaN in front, NaNs inside, a NaN at the head of every 32-chunk (where a
+    part of a split reduction may start) and behind it, +0 / -0 only, infinities, nothing to clip, all of one sign"""
+    v = rs.standard_normal((B, M)) * 10.0 ** rs.randint(-6, 6, (B, M))
+    w = rs.standard_normal((B, M))
+    for k in range(B):
+        kind = k % 8
+        if kind == 1:
+            v[k, 0] = np.nan
+        elif kind == 2:
+            v[k, rs.randint(1, M, 5)] = np.nan
+        elif kind == 3:
+            v[k, np.arange(32, M, 32)] = np.nan
+            v[k, np.arange(31, M, 32)] = np.nan
+        elif kind == 4:
+            v[k] = np.where(rs.rand(M) < .5, 0.0, -0.0)
+        elif kind == 5:
+            v[k, rs.randint(0, M, 7)] = np.inf
+            v[k, rs.randint(0, M, 7)] = -np.inf
+        elif kind == 6:
+            w[k] = np.abs(w[k])                      # no dx < 0: clp returns DBL_MAX
+        elif kind == 7:
+            v[k] = np.abs(v[k]) + 1.0
+    return v, w
+
+
+@pytest.mark.parametrize("variant", ["interp", "interp8", "ldsc4"])
+def test_long_reductions_with_nans_zeros_infinities(tmp_path, variant):
+    """the long minimum / maximum / infinity norm / clp / inner product of 600 operands -- on `interp8` evaluated as parallel
+    parts + a combining record (interp_schedule.split_long), on the LDS walk as two-level folds -- return the bits of the
+    reference's chain for operand lists with NaNs (in front, inside, at the head of every chunk), +0 / -0, infinities"""
+    import __graft_entry__ as g
+    from tenscalc_amd.problems.small import long_reductions
+    from tenscalc_amd.runtime import HipSolver
+    from tenscalc_amd.tapeio import save_tape
+    from oracle.tc_oracle import Oracle
+    spec = long_reductions(folder=g.GENERATED)
+    so = spec.build(**g.VARIANT_KW[variant])
+    if variant == "interp8":
+        src = open(so.replace("lib" + spec.classname, spec.classname).replace(".so", ".hip")).read()
+        assert "__builtin_inf()" in src          # the constants the parts of a split minimum / maximum lead with
+    B, M = 128, 600
+    rs = np.random.RandomState(33)
+    A = rs.random_sample((B, 12, 4)); b = rs.random_sample((B, 12)); x0 = .02 * rs.random_sample((B, 4)) + .005
+    At = np.ascontiguousarray(np.transpose(A, (0, 2, 1)))
+    v, w = _adversarial(B, M, rs)
+    tape = str(tmp_path / "lr.tape")
+    save_tape(spec.tape, tape)
+    c = spec.classname
+    ref, rst, rit = Oracle(tape).solve_batch({c + "_set_A": At.reshape(B, -1), c + "_set_b": b, c + "_set_x": x0,
+                                              c + "_set_v": v, c + "_set_w": w}, c + "_getOutputs", B, mu0=1e-2, maxIter=40)
+    obj = HipSolver(so, B=B, device=0)
+    obj.setP_A(At); obj.setP_b(b); obj.setV_x(x0); obj.setP_v(v); obj.setP_w(w)
+    st, it, _ = obj.solve(mu0=1e-2, maxIter=40)
+    got = np.concatenate([a.reshape(B, -1) for a in obj.getOutputs()], axis=1)
+    obj.close()
+    assert np.array_equal(st, rst) and np.array_equal(it, rit) and (st == 0).all()
+    assert got.shape == ref.shape
+    nan = np.isnan(ref)
+    assert np.array_equal(np.isnan(got), nan)
+    assert np.array_equal(got[~nan].view(np.int64), ref[~nan].view(np.int64))        # signs of zeros included
+    assert nan[:, -5:].any() and (ref[:, -5:][~nan[:, -5:]] == 0).any()               # ... and the cases were there

@@ -389,3 +389,18 @@ def test_stream_l1l2_splits_its_long_reductions(native_built, tape_oracle, tmp_p
     spec = l1l2(N=140, classname="tmp_l1l2_140", folder=str(tmp_path))
     cs = _check(spec, l1l2_data(3, N=140), tape_oracle, SOLVE_ARGS, W=8)
     assert sum(s_[3] for s_ in cs["gstats"]) >= 4
+
+
+def test_stream_long_reductions_with_nans(native_built, tape_oracle, tmp_path):
+    """problems/small.py:long_reductions on the model of the walk (W = 8: every one of its five long reductions is split), operand
+    lists with a NaN in front and at the head of every fetch chunk: each instruction's value is the oracle's (NaN where it is)"""
+    from tenscalc_amd.problems.small import long_reductions
+    spec = long_reductions(folder=str(tmp_path))
+    rs = np.random.RandomState(2)
+    v = rs.standard_normal(600); w = rs.standard_normal(600)
+    v[0] = np.nan
+    v[np.arange(32, 600, 32)] = np.nan
+    v[5:9] = [0.0, -0.0, np.inf, -np.inf]
+    data = dict(A=rs.random_sample((12, 4)), b=rs.random_sample(12), x=.02 * rs.random_sample(4) + .005, v=v, w=w)
+    cs = _check(spec, data, tape_oracle, dict(mu0=1e-2, maxIter=40), W=8)
+    assert sum(s_[3] for s_ in cs["gstats"]) == 5
